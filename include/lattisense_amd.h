@@ -1,0 +1,126 @@
+/*
+ * lattisense_amd.h — C-ABI of the MI355X executor for LattiSense's RNS polynomial-arithmetic hot path.
+ *
+ * Two layers, both plain C (pointers + sizes, no C++/torch types):
+ *
+ *  (1) OPERATOR LAYER (lsa_*): what the reference obtains from the absent HEonGPU library through
+ *      heongpu::HEContext / HEArithmeticOperator (call sites mega_ag_runners/gpu/gpu_wrapper.cu:53-138 and
+ *      mega_ag_runners/gpu/mega_ag_executors_gpu.cu:71-426).  Ciphertexts are device-resident u64 limbs laid out
+ *      [poly][limb][N] exactly like the reference's device buffers (gpu_abi_bridge_executors.h:76-80, :185-189);
+ *      every call takes a `batch` of independent ciphertexts (batch_stride u64 elements apart) and a HIP stream.
+ *
+ *  (2) TASK LAYER (create/bind/run/release_fhe_gpu_task): declared in lattisense_task.h, the drop-in for
+ *      mega_ag_runners/wrapper.h:67-85.
+ *
+ * All functions return 0 on success and a non-zero code on failure; lsa_last_error() returns the message of the
+ * last failure on the calling thread (the reference throws std::runtime_error through extern "C",
+ * gpu_abi_bridge_executors.h:51-55 — unusable from cgo/ctypes callers, SURVEY §8b "Errors").
+ * There is no CPU fallback: without a HIP device every compute entry point fails with LSA_ERR_NO_DEVICE.
+ */
+#ifndef LATTISENSE_AMD_H
+#define LATTISENSE_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lsa_context_st* lsa_context;
+typedef struct lsa_key_st* lsa_key; /* one key-switch key (relin key, or the key of one Galois element) */
+
+enum { LSA_OK = 0, LSA_ERR_ARG = 1, LSA_ERR_NO_DEVICE = 2, LSA_ERR_HIP = 3, LSA_ERR_INTERNAL = 4 };
+enum { LSA_ALGO_BFV = 0, LSA_ALGO_CKKS = 1 }; /* same values as Algo in mega_ag_runners/c_argument.h:35-38 */
+
+const char* lsa_last_error(void);
+const char* lsa_version(void);
+
+/* ---- context: replaces init_gpu_context (gpu_wrapper.cu:53-138).  q = Q chain (max_level+1 primes),
+ * p = special primes, t = BFV plaintext modulus (0 for CKKS).  Tables are built once and cached. */
+int lsa_context_create(int algo, int n, const uint64_t* q, int nq, const uint64_t* p, int np, uint64_t t,
+                       int device, lsa_context* out);
+int lsa_context_destroy(lsa_context ctx);
+/* all moduli in context order: Q chain, P, then the BFV auxiliary basis the context generated */
+int lsa_context_moduli(lsa_context ctx, uint64_t* out, int capacity, int* count);
+
+/* ---- device memory / streams (thin wrappers so a caller needs no HIP bindings; torch pointers work too) */
+int lsa_malloc(lsa_context ctx, void** dptr, size_t bytes);
+int lsa_free(lsa_context ctx, void* dptr);
+int lsa_memcpy_h2d(lsa_context ctx, void* dst, const void* src, size_t bytes, void* stream);
+int lsa_memcpy_d2h(lsa_context ctx, void* dst, const void* src, size_t bytes, void* stream);
+int lsa_memcpy_d2d(lsa_context ctx, void* dst, const void* src, size_t bytes, void* stream);
+int lsa_stream_create(lsa_context ctx, void** stream);
+int lsa_stream_destroy(lsa_context ctx, void* stream);
+int lsa_stream_synchronize(lsa_context ctx, void* stream);
+/* HIP-event timing on `stream` (bench.py roofline leg): returns elapsed ms between two recorded events */
+int lsa_event_create(lsa_context ctx, void** ev);
+int lsa_event_record(lsa_context ctx, void* ev, void* stream);
+int lsa_event_elapsed_ms(lsa_context ctx, void* ev_start, void* ev_stop, float* ms);
+int lsa_event_destroy(lsa_context ctx, void* ev);
+
+/* ---- evaluation keys.  `compact` is the ABI order of plug-in/lattigo/acc/c_struct_import_export.go:41-135:
+ * [beta][2][key_level+1+np][N], beta = ceil((key_level+1)/np), NTT domain, non-Montgomery (GPU_MFORM_BITS = 0,
+ * cxx_sdk_v2/cxx_fhe_task_gpu.cpp:30).  Replaces export_relin_key / export_galois_key / export_switching_key
+ * (gpu_abi_bridge_executors.h:86-176). */
+int lsa_key_upload(lsa_context ctx, const uint64_t* compact_host, int key_level, void* stream, lsa_key* out);
+/* adopt a device buffer already holding the compact key (e.g. after an RCCL broadcast); converted in place */
+int lsa_key_adopt_device(lsa_context ctx, uint64_t* compact_dev, int key_level, void* stream, lsa_key* out);
+int lsa_key_destroy(lsa_context ctx, lsa_key key);
+size_t lsa_key_bytes(lsa_context ctx, int key_level);
+
+/* ---- K1/K2: batched negacyclic NTT / INTT, in place.  data = [batch][rows][N]; row r uses modulus index
+ * mod_of[r % period] in context order (0xFF = leave the row untouched). */
+int lsa_ntt(lsa_context ctx, uint64_t* data, int batch, long long batch_stride, int rows, const int* mod_of,
+            int period, int inverse, void* stream);
+
+/* ---- K3: limb-wise add / sub / negate over `polys` polynomials of level+1 limbs (ct+ct, ct-ct, -ct).
+ * op: 0 add, 1 sub, 2 neg (b ignored).  Replaces HEArithmeticOperator::add/sub/negate (executors_gpu.cu:79-173). */
+int lsa_poly_addsub(lsa_context ctx, int op, int level, int polys, const uint64_t* a, const uint64_t* b,
+                    uint64_t* out, int batch, long long stride_a, long long stride_b, long long stride_out,
+                    void* stream);
+
+/* ---- CKKS (NTT-domain ciphertexts) ---------------------------------------------------------------------- */
+/* multiply (executors_gpu.cu:185,223): a,b = [2][L][N] -> d3 = [3][L][N] */
+int lsa_ckks_mult(lsa_context ctx, int level, const uint64_t* a, const uint64_t* b, uint64_t* d3, int batch,
+                  long long stride_a, long long stride_b, long long stride_d, void* stream);
+/* relinearize (executors_gpu.cu:236): d3 -> out [2][L][N] */
+int lsa_ckks_relin(lsa_context ctx, int level, const uint64_t* d3, lsa_key rlk, uint64_t* out, int batch,
+                   long long stride_d, long long stride_out, void* stream);
+/* rescale (executors_gpu.cu:246): in [polys][L][N] -> out [polys][L-1][N] */
+int lsa_ckks_rescale(lsa_context ctx, int level, int polys, const uint64_t* in, uint64_t* out, int batch,
+                     long long stride_in, long long stride_out, void* stream);
+/* rotate_rows / conjugate (executors_gpu.cu:275,289): Galois element g, key of that element */
+int lsa_ckks_rotate(lsa_context ctx, int level, const uint64_t* in, uint64_t galois_element, lsa_key glk,
+                    uint64_t* out, int batch, long long stride_in, long long stride_out, void* stream);
+/* mod_drop (executors_gpu.cu:257): keep the first L-1 limbs of each polynomial */
+int lsa_drop_level(lsa_context ctx, int level, int polys, const uint64_t* in, uint64_t* out, int batch,
+                   long long stride_in, long long stride_out, void* stream);
+/* fused HMult + relinearize + rescale: the BASELINE.json headline operator. out = [2][L-1][N] */
+int lsa_ckks_mult_relin_rescale(lsa_context ctx, int level, const uint64_t* a, const uint64_t* b, lsa_key rlk,
+                                uint64_t* out, int batch, long long stride_a, long long stride_b,
+                                long long stride_out, void* stream);
+
+/* ---- BFV (coefficient-domain ciphertexts) ---------------------------------------------------------------- */
+int lsa_bfv_mult(lsa_context ctx, int level, const uint64_t* a, const uint64_t* b, uint64_t* d3, int batch,
+                 long long stride_a, long long stride_b, long long stride_d, void* stream);
+int lsa_bfv_relin(lsa_context ctx, int level, const uint64_t* d3, lsa_key rlk, uint64_t* out, int batch,
+                  long long stride_d, long long stride_out, void* stream);
+int lsa_bfv_rotate(lsa_context ctx, int level, const uint64_t* in, uint64_t galois_element, lsa_key glk,
+                   uint64_t* out, int batch, long long stride_in, long long stride_out, void* stream);
+int lsa_bfv_rescale(lsa_context ctx, int level, int polys, const uint64_t* in, uint64_t* out, int batch,
+                    long long stride_in, long long stride_out, void* stream);
+int lsa_bfv_mult_relin(lsa_context ctx, int level, const uint64_t* a, const uint64_t* b, lsa_key rlk,
+                       uint64_t* out, int batch, long long stride_a, long long stride_b, long long stride_out,
+                       void* stream);
+
+/* ---- tuning / introspection */
+/* ciphertexts processed per kernel wave inside the fused operators (0 = automatic) */
+int lsa_set_tile_batch(lsa_context ctx, int tile_batch);
+/* micro-benchmark kernels used by bench.py / DESIGN.md to report the integer-multiply and copy ceilings */
+int lsa_probe_copy(lsa_context ctx, uint64_t* dst, const uint64_t* src, size_t n_u64, void* stream);
+int lsa_probe_mulhi(lsa_context ctx, uint64_t* buf, size_t n_u64, int iters, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""ctypes binding of liblattisense_amd.so (the C-ABI of include/lattisense_amd.h).
+
+Host-side plumbing only: every compute call goes to the HIP library; there is no Python/NumPy fallback —
+if the library or a GPU is missing the calls raise.
+"""
+import ctypes
+import importlib.util
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblattisense_amd.so")
+
+_lib = None
+
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_ll = ctypes.c_longlong
+c_vp = ctypes.c_void_p
+c_int = ctypes.c_int
+
+
+class LsaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lattisense_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _preload_hip_runtime():
+    """Load the HIP runtime torch bundles (if torch is installed) before our library, so that a process that also
+    imports torch (RCCL, device tensors) ends up with exactly one HIP runtime."""
+    spec = importlib.util.find_spec("torch")
+    if spec is not None and spec.origin:
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+
+
+SIGNATURES = {
+    # name: (restype, argtypes)
+    "lsa_last_error": (ctypes.c_char_p, []),
+    "lsa_version": (ctypes.c_char_p, []),
+    "lsa_context_create": (c_int, [c_int, c_int, c_u64p, c_int, c_u64p, c_int, ctypes.c_uint64, c_int,
+                                   ctypes.POINTER(c_vp)]),
+    "lsa_context_destroy": (c_int, [c_vp]),
+    "lsa_context_moduli": (c_int, [c_vp, c_u64p, c_int, ctypes.POINTER(c_int)]),
+    "lsa_malloc": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.c_size_t]),
+    "lsa_free": (c_int, [c_vp, c_vp]),
+    "lsa_memcpy_h2d": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lsa_memcpy_d2h": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lsa_memcpy_d2d": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lsa_stream_create": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
+    "lsa_stream_destroy": (c_int, [c_vp, c_vp]),
+    "lsa_stream_synchronize": (c_int, [c_vp, c_vp]),
+    "lsa_event_create": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
+    "lsa_event_record": (c_int, [c_vp, c_vp, c_vp]),
+    "lsa_event_elapsed_ms": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_float)]),
+    "lsa_event_destroy": (c_int, [c_vp, c_vp]),
+    "lsa_key_upload": (c_int, [c_vp, c_vp, c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "lsa_key_adopt_device": (c_int, [c_vp, c_vp, c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "lsa_key_destroy": (c_int, [c_vp, c_vp]),
+    "lsa_key_bytes": (ctypes.c_size_t, [c_vp, c_int]),
+    "lsa_ntt": (c_int, [c_vp, c_vp, c_int, c_ll, c_int, ctypes.POINTER(c_int), c_int, c_int, c_vp]),
+    "lsa_poly_addsub": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_ll, c_ll, c_ll, c_vp]),
+    "lsa_ckks_mult": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_ll, c_ll, c_ll, c_vp]),
+    "lsa_ckks_relin": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_ll, c_ll, c_vp]),
+    "lsa_ckks_rescale": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_ll, c_ll, c_vp]),
+    "lsa_ckks_rotate": (c_int, [c_vp, c_int, c_vp, ctypes.c_uint64, c_vp, c_vp, c_int, c_ll, c_ll, c_vp]),
+    "lsa_drop_level": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_ll, c_ll, c_vp]),
+    "lsa_ckks_mult_relin_rescale": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_ll, c_ll, c_vp]),
+    "lsa_bfv_mult": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_ll, c_ll, c_ll, c_vp]),
+    "lsa_bfv_relin": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_ll, c_ll, c_vp]),
+    "lsa_bfv_rotate": (c_int, [c_vp, c_int, c_vp, ctypes.c_uint64, c_vp, c_vp, c_int, c_ll, c_ll, c_vp]),
+    "lsa_bfv_rescale": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_ll, c_ll, c_vp]),
+    "lsa_bfv_mult_relin": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_ll, c_ll, c_vp]),
+    "lsa_set_tile_batch": (c_int, [c_vp, c_int]),
+    "lsa_probe_copy": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "lsa_probe_mulhi": (c_int, [c_vp, c_vp, ctypes.c_size_t, c_int, c_vp]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("liblattisense_amd.so is not built: run `python -m lattisense_amd.build` "
+                               "(or __graft_entry__.build()); there is no fallback path")
+        _preload_hip_runtime()
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here == the .so does not export what the header declares
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise LsaError(rc, lib().lsa_last_error().decode())

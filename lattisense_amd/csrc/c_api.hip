@@ -1,0 +1,314 @@
+// c_api.hip — extern "C" operator layer (include/lattisense_amd.h).  Every entry point converts C++ exceptions into
+// error codes: nothing throws across the C boundary (the reference does, SURVEY §8b "Errors").
+#include "lsa_internal.h"
+
+namespace lsa {
+void ckks_mult(Context&, int, const u64*, const u64*, u64*, int, long long, long long, long long, hipStream_t);
+void ckks_relin(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
+void ckks_rescale(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
+void ckks_rotate(Context&, int, const u64*, u64, const Key&, u64*, int, long long, long long, hipStream_t);
+void ckks_mult_relin_rescale(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long,
+                             long long, hipStream_t);
+void drop_level(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
+void poly_addsub(Context&, int, int, int, const u64*, const u64*, u64*, int, long long, long long, long long,
+                 hipStream_t);
+void bfv_mult(Context&, int, const u64*, const u64*, u64*, int, long long, long long, long long, hipStream_t);
+void bfv_relin(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
+void bfv_rotate(Context&, int, const u64*, u64, const Key&, u64*, int, long long, long long, hipStream_t);
+void bfv_rescale(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
+}  // namespace lsa
+
+using namespace lsa;
+
+struct lsa_context_st {
+    Context ctx;
+    lsa_context_st(int algo, int n, const u64* q, int nq, const u64* p, int np, u64 t, int dev)
+        : ctx(algo, n, q, nq, p, np, t, dev) {}
+};
+struct lsa_key_st {
+    Key key;
+};
+
+template <typename F>
+static int guard(F&& f) {
+    try {
+        f();
+        return LSA_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return LSA_ERR_INTERNAL;
+    } catch (...) {
+        set_last_error("unknown error");
+        return LSA_ERR_INTERNAL;
+    }
+}
+
+static Context& C(lsa_context h) {
+    LSA_REQUIRE(h != nullptr, "null context");
+    h->ctx.use_device();
+    return h->ctx;
+}
+static const Key& K(lsa_key k) {
+    LSA_REQUIRE(k != nullptr && k->key.data != nullptr, "null key");
+    return k->key;
+}
+static hipStream_t S(void* s) { return (hipStream_t)s; }
+
+extern "C" {
+
+const char* lsa_last_error(void) { return last_error().c_str(); }
+const char* lsa_version(void) { return "lattisense_amd 0.1 (gfx950)"; }
+
+int lsa_context_create(int algo, int n, const uint64_t* q, int nq, const uint64_t* p, int np, uint64_t t, int device,
+                       lsa_context* out) {
+    return guard([&] {
+        LSA_REQUIRE(out != nullptr && q != nullptr && (np == 0 || p != nullptr), "null argument");
+        *out = new lsa_context_st(algo, n, q, nq, p, np, t, device);
+    });
+}
+int lsa_context_destroy(lsa_context ctx) {
+    return guard([&] { delete ctx; });
+}
+int lsa_context_moduli(lsa_context ctx, uint64_t* out, int capacity, int* count) {
+    return guard([&] {
+        Context& c = C(ctx);
+        if (count) *count = c.nmod;
+        for (int i = 0; i < c.nmod && i < capacity; i++) out[i] = c.T.mod[i];
+    });
+}
+
+int lsa_malloc(lsa_context ctx, void** dptr, size_t bytes) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipMalloc(dptr, bytes));
+    });
+}
+int lsa_free(lsa_context ctx, void* dptr) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipFree(dptr));
+    });
+}
+int lsa_memcpy_h2d(lsa_context ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
+    });
+}
+int lsa_memcpy_d2h(lsa_context ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream)));
+        LSA_HIP(hipStreamSynchronize(S(stream)));
+    });
+}
+int lsa_memcpy_d2d(lsa_context ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(stream)));
+    });
+}
+int lsa_stream_create(lsa_context ctx, void** stream) {
+    return guard([&] {
+        C(ctx);
+        hipStream_t s;
+        LSA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        *stream = (void*)s;
+    });
+}
+int lsa_stream_destroy(lsa_context ctx, void* stream) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipStreamDestroy(S(stream)));
+    });
+}
+int lsa_stream_synchronize(lsa_context ctx, void* stream) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipStreamSynchronize(S(stream)));
+    });
+}
+int lsa_event_create(lsa_context ctx, void** ev) {
+    return guard([&] {
+        C(ctx);
+        hipEvent_t e;
+        LSA_HIP(hipEventCreate(&e));
+        *ev = (void*)e;
+    });
+}
+int lsa_event_record(lsa_context ctx, void* ev, void* stream) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipEventRecord((hipEvent_t)ev, S(stream)));
+    });
+}
+int lsa_event_elapsed_ms(lsa_context ctx, void* ev_start, void* ev_stop, float* ms) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
+        LSA_HIP(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    });
+}
+int lsa_event_destroy(lsa_context ctx, void* ev) {
+    return guard([&] {
+        C(ctx);
+        LSA_HIP(hipEventDestroy((hipEvent_t)ev));
+    });
+}
+
+// ---- keys
+size_t lsa_key_bytes(lsa_context ctx, int key_level) {
+    if (!ctx) return 0;
+    const Context& c = ctx->ctx;
+    if (c.np < 1 || key_level < 0 || key_level >= c.nq) return 0;
+    const size_t beta = (key_level + 1 + c.np - 1) / c.np;
+    return beta * 2 * (size_t)(key_level + 1 + c.np) * c.n * sizeof(u64);
+}
+
+static void key_to_mont(Context& c, Key& k, hipStream_t s) {
+    const int comp = k.level + 1 + c.np;
+    const int beta = (k.level + 1 + c.np - 1) / c.np;
+    RowMap rm;
+    rm.period = comp;
+    LSA_REQUIRE(comp <= LSA_MAX_PERIOD, "key has too many limbs");
+    for (int j = 0; j < comp; j++) rm.mod_of[j] = (unsigned char)(j <= k.level ? j : c.p_mod(j - k.level - 1));
+    launch_to_mont(c, k.data, beta * 2 * comp, rm, s);
+}
+
+int lsa_key_upload(lsa_context ctx, const uint64_t* compact_host, int key_level, void* stream, lsa_key* out) {
+    return guard([&] {
+        Context& c = C(ctx);
+        LSA_REQUIRE(out != nullptr && compact_host != nullptr, "null argument");
+        const size_t bytes = lsa_key_bytes(ctx, key_level);
+        LSA_REQUIRE(bytes > 0, "bad key level (or context has no special primes)");
+        auto k = std::make_unique<lsa_key_st>();
+        k->key.level = key_level;
+        k->key.owned = true;
+        LSA_HIP(hipMalloc((void**)&k->key.data, bytes));
+        LSA_HIP(hipMemcpyAsync(k->key.data, compact_host, bytes, hipMemcpyHostToDevice, S(stream)));
+        key_to_mont(c, k->key, S(stream));
+        LSA_HIP(hipStreamSynchronize(S(stream)));  // host buffer may be released by the caller on return
+        *out = k.release();
+    });
+}
+int lsa_key_adopt_device(lsa_context ctx, uint64_t* compact_dev, int key_level, void* stream, lsa_key* out) {
+    return guard([&] {
+        Context& c = C(ctx);
+        LSA_REQUIRE(out != nullptr && compact_dev != nullptr, "null argument");
+        LSA_REQUIRE(lsa_key_bytes(ctx, key_level) > 0, "bad key level (or context has no special primes)");
+        auto k = std::make_unique<lsa_key_st>();
+        k->key.level = key_level;
+        k->key.owned = false;
+        k->key.data = compact_dev;
+        key_to_mont(c, k->key, S(stream));
+        *out = k.release();
+    });
+}
+int lsa_key_destroy(lsa_context ctx, lsa_key key) {
+    return guard([&] {
+        C(ctx);
+        if (key) {
+            if (key->key.owned && key->key.data) LSA_HIP(hipFree(key->key.data));
+            delete key;
+        }
+    });
+}
+
+// ---- polynomial ops
+int lsa_ntt(lsa_context ctx, uint64_t* data, int batch, long long batch_stride, int rows, const int* mod_of, int period,
+            int inverse, void* stream) {
+    return guard([&] {
+        Context& c = C(ctx);
+        LSA_REQUIRE(data && mod_of && period >= 1 && period <= LSA_MAX_PERIOD, "bad arguments");
+        RowMap rm;
+        rm.period = period;
+        for (int i = 0; i < period; i++) {
+            LSA_REQUIRE(mod_of[i] == LSA_ROW_SKIP || (mod_of[i] >= 0 && mod_of[i] < c.nmod), "modulus index out of range");
+            rm.mod_of[i] = (unsigned char)mod_of[i];
+        }
+        launch_ntt(c, data, data, batch, batch_stride, rows, rm, inverse != 0, S(stream));
+    });
+}
+int lsa_poly_addsub(lsa_context ctx, int op, int level, int polys, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                    int batch, long long sa, long long sb, long long so, void* stream) {
+    return guard([&] { poly_addsub(C(ctx), op, level, polys, a, b, out, batch, sa, sb, so, S(stream)); });
+}
+
+// ---- CKKS
+int lsa_ckks_mult(lsa_context ctx, int level, const uint64_t* a, const uint64_t* b, uint64_t* d3, int batch,
+                  long long sa, long long sb, long long sd, void* stream) {
+    return guard([&] { ckks_mult(C(ctx), level, a, b, d3, batch, sa, sb, sd, S(stream)); });
+}
+int lsa_ckks_relin(lsa_context ctx, int level, const uint64_t* d3, lsa_key rlk, uint64_t* out, int batch, long long sd,
+                   long long so, void* stream) {
+    return guard([&] { ckks_relin(C(ctx), level, d3, K(rlk), out, batch, sd, so, S(stream)); });
+}
+int lsa_ckks_rescale(lsa_context ctx, int level, int polys, const uint64_t* in, uint64_t* out, int batch, long long si,
+                     long long so, void* stream) {
+    return guard([&] { ckks_rescale(C(ctx), level, polys, in, out, batch, si, so, S(stream)); });
+}
+int lsa_ckks_rotate(lsa_context ctx, int level, const uint64_t* in, uint64_t g, lsa_key glk, uint64_t* out, int batch,
+                    long long si, long long so, void* stream) {
+    return guard([&] { ckks_rotate(C(ctx), level, in, g, K(glk), out, batch, si, so, S(stream)); });
+}
+int lsa_drop_level(lsa_context ctx, int level, int polys, const uint64_t* in, uint64_t* out, int batch, long long si,
+                   long long so, void* stream) {
+    return guard([&] { drop_level(C(ctx), level, polys, in, out, batch, si, so, S(stream)); });
+}
+int lsa_ckks_mult_relin_rescale(lsa_context ctx, int level, const uint64_t* a, const uint64_t* b, lsa_key rlk,
+                                uint64_t* out, int batch, long long sa, long long sb, long long so, void* stream) {
+    return guard([&] { ckks_mult_relin_rescale(C(ctx), level, a, b, K(rlk), out, batch, sa, sb, so, S(stream)); });
+}
+
+// ---- BFV
+int lsa_bfv_mult(lsa_context ctx, int level, const uint64_t* a, const uint64_t* b, uint64_t* d3, int batch, long long sa,
+                 long long sb, long long sd, void* stream) {
+    return guard([&] { bfv_mult(C(ctx), level, a, b, d3, batch, sa, sb, sd, S(stream)); });
+}
+int lsa_bfv_relin(lsa_context ctx, int level, const uint64_t* d3, lsa_key rlk, uint64_t* out, int batch, long long sd,
+                  long long so, void* stream) {
+    return guard([&] { bfv_relin(C(ctx), level, d3, K(rlk), out, batch, sd, so, S(stream)); });
+}
+int lsa_bfv_rotate(lsa_context ctx, int level, const uint64_t* in, uint64_t g, lsa_key glk, uint64_t* out, int batch,
+                   long long si, long long so, void* stream) {
+    return guard([&] { bfv_rotate(C(ctx), level, in, g, K(glk), out, batch, si, so, S(stream)); });
+}
+int lsa_bfv_rescale(lsa_context ctx, int level, int polys, const uint64_t* in, uint64_t* out, int batch, long long si,
+                    long long so, void* stream) {
+    return guard([&] { bfv_rescale(C(ctx), level, polys, in, out, batch, si, so, S(stream)); });
+}
+int lsa_bfv_mult_relin(lsa_context ctx, int level, const uint64_t* a, const uint64_t* b, lsa_key rlk, uint64_t* out,
+                       int batch, long long sa, long long sb, long long so, void* stream) {
+    return guard([&] {
+        Context& c = C(ctx);
+        const long long sd = 3LL * (level + 1) * c.n;
+        // d3 lives in the second arena so that the two pipelines' own arena use cannot overlap it
+        u64* d3 = c.workspace2((size_t)sd * batch, S(stream));
+        bfv_mult(c, level, a, b, d3, batch, sa, sb, sd, S(stream));
+        bfv_relin(c, level, d3, K(rlk), out, batch, sd, so, S(stream));
+    });
+}
+
+int lsa_set_tile_batch(lsa_context ctx, int tile_batch) {
+    return guard([&] {
+        LSA_REQUIRE(tile_batch >= 0, "tile_batch must be >= 0");
+        C(ctx).tile_batch = tile_batch;
+    });
+}
+int lsa_probe_copy(lsa_context ctx, uint64_t* dst, const uint64_t* src, size_t n_u64, void* stream) {
+    return guard([&] {
+        C(ctx);
+        launch_probe_copy(dst, src, n_u64, S(stream));
+    });
+}
+int lsa_probe_mulhi(lsa_context ctx, uint64_t* buf, size_t n_u64, int iters, void* stream) {
+    return guard([&] {
+        C(ctx);
+        launch_probe_mulhi(buf, n_u64, iters, S(stream));
+    });
+}
+
+}  // extern "C"

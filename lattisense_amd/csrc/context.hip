@@ -1,0 +1,204 @@
+// context.hip — parameter-set context: device tables, cached conversion plans, workspace.
+#include "lsa_internal.h"
+
+namespace lsa {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+const std::string& last_error() { return g_last_error; }
+
+Context::Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_, u64 t_, int device_)
+    : algo(algo_), n(n_), nq(nq_), np(np_), device(device_), t(t_) {
+    LSA_REQUIRE(algo == LSA_ALGO_BFV || algo == LSA_ALGO_CKKS, "unknown algorithm");
+    LSA_REQUIRE(n >= 512 && n <= (1 << 17) && (n & (n - 1)) == 0, "ring degree must be a power of two in [2^9, 2^17]");
+    LSA_REQUIRE(nq >= 1 && np >= 0 && np <= LSA_BC_MAX_SRC, "bad modulus chain lengths");
+    std::vector<u64> mods(q, q + nq);
+    mods.insert(mods.end(), p, p + np);
+    nmul = 0;
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    if (algo == LSA_ALGO_BFV) {
+        LSA_REQUIRE(t > 1, "BFV needs a plaintext modulus");
+        nmul = bfv_aux_count(q, nq, lg);
+        std::vector<u64> aux = gen_aux_primes(n, nmul, mods);
+        mods.insert(mods.end(), aux.begin(), aux.end());
+    }
+    nmod = (int)mods.size();
+    LSA_REQUIRE(nmod < LSA_ROW_SKIP, "too many moduli");
+    T.build(n, mods);
+    logn = T.logn;
+    plan = make_ntt_plan(logn, 12);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        throw Error(LSA_ERR_NO_DEVICE, "no HIP device available: this library has no CPU fallback");
+    LSA_REQUIRE(device >= 0 && device < ndev, "device index out of range");
+    use_device();
+    const size_t tw_bytes = (size_t)nmod * n * sizeof(u64);
+    LSA_HIP(hipMalloc((void**)&d_mods, nmod * sizeof(ModDev)));
+    LSA_HIP(hipMalloc((void**)&d_psi, tw_bytes));
+    LSA_HIP(hipMalloc((void**)&d_psiinv, tw_bytes));
+    LSA_HIP(hipMalloc((void**)&d_scale, (size_t)nmod * 2 * sizeof(u64)));
+    LSA_HIP(hipMemcpy(d_mods, T.mods.data(), nmod * sizeof(ModDev), hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_psi, T.psi.data(), tw_bytes, hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_psiinv, T.psiinv.data(), tw_bytes, hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_scale, T.scale.data(), (size_t)nmod * 2 * sizeof(u64), hipMemcpyHostToDevice));
+}
+
+Context::~Context() {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d_mods);
+    (void)hipFree(d_psi);
+    (void)hipFree(d_psiinv);
+    (void)hipFree(d_scale);
+    (void)hipFree(ws);
+    (void)hipFree(ws2);
+    for (auto& kv : bconv) (void)hipFree(kv.second);
+    for (auto& kv : perm_ntt) (void)hipFree(kv.second);
+    for (auto& kv : perm_coeff) (void)hipFree(kv.second);
+    for (auto& kv : consts) (void)hipFree(kv.second);
+}
+
+u64* Context::workspace(size_t words, hipStream_t s) {
+    if (words > ws_words) {
+        // growing: earlier users of the arena were enqueued on `s` (one in-flight operator per context)
+        LSA_HIP(hipStreamSynchronize(s));
+        if (ws) LSA_HIP(hipFree(ws));
+        ws = nullptr;
+        ws_words = 0;
+        LSA_HIP(hipMalloc((void**)&ws, words * sizeof(u64)));
+        ws_words = words;
+    }
+    return ws;
+}
+
+u64* Context::workspace2(size_t words, hipStream_t s) {
+    if (words > ws2_words) {
+        LSA_HIP(hipStreamSynchronize(s));
+        if (ws2) LSA_HIP(hipFree(ws2));
+        ws2 = nullptr;
+        ws2_words = 0;
+        LSA_HIP(hipMalloc((void**)&ws2, words * sizeof(u64)));
+        ws2_words = words;
+    }
+    return ws2;
+}
+
+const BaseConvConsts* Context::baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered) {
+    std::string key = centered ? "c" : "u";
+    for (int x : src) key += "|" + std::to_string(x);
+    key += "->";
+    for (int x : dst) key += "|" + std::to_string(x);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = bconv.find(key);
+    if (it != bconv.end()) return it->second;
+    const int ns = (int)src.size(), nd = (int)dst.size();
+    LSA_REQUIRE(ns >= 1 && ns <= LSA_BC_MAX_SRC && nd >= 1 && nd <= LSA_BC_MAX_DST, "base conversion too wide");
+    auto K = std::make_unique<BaseConvConsts>();
+    K->ns = ns;
+    K->nd = nd;
+    K->centered = centered ? 1 : 0;
+    for (int i = 0; i < ns; i++) {
+        const u64 qi = T.mod[src[i]];
+        K->src_mod[i] = src[i];
+        u64 pr = 1 % qi;
+        for (int l = 0; l < ns; l++)
+            if (l != i) pr = mul_mod_host(pr, T.mod[src[l]] % qi, qi);
+        K->shat_inv_m[i] = to_mont_host(inv_mod(pr, qi), qi);
+        K->half_src[i] = mul_mod_host(qi - 1, (qi + 1) >> 1, qi);  // floor(S/2) mod q_i with S == 0 mod q_i, S odd
+        K->qf[i] = (double)qi;
+    }
+    for (int j = 0; j < nd; j++) {
+        const u64 pj = T.mod[dst[j]];
+        K->dst_mod[j] = dst[j];
+        u64 all = 1 % pj;
+        for (int l = 0; l < ns; l++) all = mul_mod_host(all, T.mod[src[l]] % pj, pj);
+        for (int i = 0; i < ns; i++) {
+            u64 pr = 1 % pj;
+            for (int l = 0; l < ns; l++)
+                if (l != i) pr = mul_mod_host(pr, T.mod[src[l]] % pj, pj);
+            K->shat_m[j][i] = to_mont_host(pr, pj);
+        }
+        for (int v = 0; v <= ns; v++) K->vs[j][v] = mul_mod_host((u64)v % pj, all, pj);
+        K->half_dst[j] = mul_mod_host((all + pj - 1 % pj) % pj, (pj + 1) >> 1, pj);
+    }
+    use_device();
+    BaseConvConsts* d = nullptr;
+    LSA_HIP(hipMalloc((void**)&d, sizeof(BaseConvConsts)));
+    LSA_HIP(hipMemcpy(d, K.get(), sizeof(BaseConvConsts), hipMemcpyHostToDevice));
+    bconv[key] = d;
+    return d;
+}
+
+static unsigned brv_bits(unsigned x, int bits) {
+    unsigned r = 0;
+    for (int i = 0; i < bits; i++) {
+        r = (r << 1) | (x & 1);
+        x >>= 1;
+    }
+    return r;
+}
+
+// NTT-domain automorphism X -> X^g as a gather table: out[i] = in[perm[i]]
+const u32* Context::ntt_perm(u64 g) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = perm_ntt.find(g);
+    if (it != perm_ntt.end()) return it->second;
+    LSA_REQUIRE((g & 1) == 1 && g < 2 * (u64)n, "Galois element must be odd and < 2N");
+    std::vector<u32> h(n);
+    const u64 mask = 2 * (u64)n - 1;
+    for (int i = 0; i < n; i++) {
+        const u64 e = 2 * (u64)brv_bits((unsigned)i, logn) + 1;
+        const u64 e2 = (g * e) & mask;
+        h[i] = brv_bits((unsigned)((e2 - 1) >> 1), logn);
+    }
+    use_device();
+    u32* d = nullptr;
+    LSA_HIP(hipMalloc((void**)&d, n * sizeof(u32)));
+    LSA_HIP(hipMemcpy(d, h.data(), n * sizeof(u32), hipMemcpyHostToDevice));
+    perm_ntt[g] = d;
+    return d;
+}
+
+// coefficient-domain automorphism as a gather with sign: out[o] = (+/-) in[src(o)], bit 31 = negate
+const u32* Context::coeff_perm(u64 g) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = perm_coeff.find(g);
+    if (it != perm_coeff.end()) return it->second;
+    LSA_REQUIRE((g & 1) == 1 && g < 2 * (u64)n, "Galois element must be odd and < 2N");
+    std::vector<u32> h(n);
+    const u64 mask = 2 * (u64)n - 1;
+    for (int i = 0; i < n; i++) {
+        u64 idx = ((u64)i * g) & mask;
+        u32 sign = 0;
+        if (idx >= (u64)n) {
+            idx -= n;
+            sign = 1u << 31;
+        }
+        h[idx] = (u32)i | sign;
+    }
+    use_device();
+    u32* d = nullptr;
+    LSA_HIP(hipMalloc((void**)&d, n * sizeof(u32)));
+    LSA_HIP(hipMemcpy(d, h.data(), n * sizeof(u32), hipMemcpyHostToDevice));
+    perm_coeff[g] = d;
+    return d;
+}
+
+const u64* Context::const_vec(const std::string& name, const std::vector<int>& mods, const std::vector<u64>& vals) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = consts.find(name);
+    if (it != consts.end()) return it->second;
+    std::vector<u64> m(vals.size());
+    for (size_t i = 0; i < vals.size(); i++) m[i] = to_mont_host(vals[i] % T.mod[mods[i]], T.mod[mods[i]]);
+    use_device();
+    u64* d = nullptr;
+    LSA_HIP(hipMalloc((void**)&d, m.size() * sizeof(u64)));
+    LSA_HIP(hipMemcpy(d, m.data(), m.size() * sizeof(u64), hipMemcpyHostToDevice));
+    consts[name] = d;
+    return d;
+}
+
+}  // namespace lsa

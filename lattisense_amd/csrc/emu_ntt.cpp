@@ -1,0 +1,54 @@
+// emu_ntt.cpp — CPU replay of the NTT kernel's phase functions, one simulated thread at a time
+// (g++ -DLSA_EMULATE).  Debugging aid for the kernel's indexing; used only by tests/test_emulate_ntt.py.
+#define LSA_EMULATE 1
+#include <vector>
+#include "ntt_plan.h"
+#include "tables.h"
+
+extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int batch, long long batch_stride, int rows,
+                           const unsigned char* mod_of, int period, int inverse, int tau_max) {
+    lsa::HostTables T;
+    T.build(n, std::vector<u64>(moduli, moduli + nmod));
+    NttPlan plan = make_ntt_plan(T.logn, tau_max);
+    NttPassArgs a{};
+    a.src = data;
+    a.dst = data;
+    a.src_stride = batch_stride;
+    a.dst_stride = batch_stride;
+    a.batch = batch;
+    a.rows = rows;
+    a.mods = T.mods.data();
+    a.tw = inverse ? T.psiinv.data() : T.psi.data();
+    a.scale = T.scale.data();
+    a.period = period;
+    for (int i = 0; i < period; i++) a.mod_of[i] = mod_of[i];
+    for (int step = 0; step < plan.npass; step++) {
+        int k = inverse ? plan.npass - 1 - step : step;
+        ntt_fill_pass(a, plan, T.logn, k, inverse);
+        std::vector<u64> lds(lds_words(a.tau));
+        long long nblocks = (long long)batch * rows * (1 << (a.logn - a.tau));
+        for (long long bid = 0; bid < nblocks; bid++) {
+            NttBlockCtx bc = ntt_decode_block(a, bid);
+            if (bc.mod == LSA_ROW_SKIP) continue;
+            for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_load(a, bc, t, lds.data());
+            int np = (a.mu + 3) / 4, base = a.mu / np, extra = a.mu % np;
+            if (!inverse) {
+                int sig = 0;
+                for (int i = 0; i < np; i++) {
+                    int rho = base + (i < extra ? 1 : 0);
+                    for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_sub_dyn(a, bc, t, lds.data(), sig, rho);
+                    sig += rho;
+                }
+            } else {
+                int sig = a.mu;
+                for (int i = np - 1; i >= 0; i--) {
+                    int rho = base + (i < extra ? 1 : 0);
+                    sig -= rho;
+                    for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_sub_dyn(a, bc, t, lds.data(), sig, rho);
+                }
+            }
+            for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_store(a, bc, t, lds.data());
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,690 @@
+// kernels.hip — hand-written gfx950 kernels for the RNS hot path and their launchers.
+// HBM-bound integer work: 16 B/lane coalesced accesses, LDS-staged butterflies, no MFMA (no dense FP contraction here).
+#include "lsa_internal.h"
+
+namespace lsa {
+
+static constexpr int TPB = 256;
+
+// ------------------------------------------------------------------------------------------------ K1/K2 NTT pass
+__global__ __launch_bounds__(LSA_NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
+    if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
+    const int tid = threadIdx.x;
+    ntt_phase_load(a, bc, tid, lds);
+    __syncthreads();
+    const int np = (a.mu + 3) / 4, base = a.mu / np, extra = a.mu % np;
+    if (!a.inverse) {
+        int sig = 0;
+        for (int i = 0; i < np; i++) {
+            const int rho = base + (i < extra ? 1 : 0);
+            ntt_phase_sub_dyn(a, bc, tid, lds, sig, rho);
+            __syncthreads();
+            sig += rho;
+        }
+    } else {
+        int sig = a.mu;
+        for (int i = np - 1; i >= 0; i--) {
+            const int rho = base + (i < extra ? 1 : 0);
+            sig -= rho;
+            ntt_phase_sub_dyn(a, bc, tid, lds, sig, rho);
+            __syncthreads();
+        }
+    }
+    ntt_phase_store(a, bc, tid, lds);
+}
+
+void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch_stride, int rows, const RowMap& rm,
+                bool inverse, hipStream_t s) {
+    launch_ntt(c, src, dst, batch, batch_stride, batch_stride, rows, rm, inverse, s);
+}
+
+void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
+                const RowMap& rm, bool inverse, hipStream_t s) {
+    if (batch <= 0 || rows <= 0) return;
+    LSA_REQUIRE(rm.period >= 1 && rm.period <= LSA_MAX_PERIOD, "ntt: bad row-map period");
+    NttPassArgs a{};
+    a.batch = batch;
+    a.rows = rows;
+    a.mods = c.d_mods;
+    a.tw = inverse ? c.d_psiinv : c.d_psi;
+    a.scale = c.d_scale;
+    a.period = rm.period;
+    for (int i = 0; i < rm.period; i++) {
+        LSA_REQUIRE(rm.mod_of[i] == LSA_ROW_SKIP || rm.mod_of[i] < c.nmod, "ntt: modulus index out of range");
+        a.mod_of[i] = rm.mod_of[i];
+    }
+    for (int step = 0; step < c.plan.npass; step++) {
+        const int k = inverse ? c.plan.npass - 1 - step : step;
+        ntt_fill_pass(a, c.plan, c.logn, k, inverse ? 1 : 0);
+        a.src = step == 0 ? src : dst;
+        a.src_stride = step == 0 ? src_stride : dst_stride;
+        a.dst = dst;
+        a.dst_stride = dst_stride;
+        const long long nblocks = (long long)batch * rows * (1 << (a.logn - a.tau));
+        LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
+        const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
+        LSA_HIP(hipGetLastError());
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise (K3/K4)
+struct EwArgs {
+    const u64* a;
+    const u64* b;
+    u64* out;
+    long long sa, sb, so;
+    const ModDev* mods;
+    int rows, logn, op, period;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+
+__device__ __forceinline__ ulonglong2 ld2(const u64* p) { return *reinterpret_cast<const ulonglong2*>(p); }
+__device__ __forceinline__ void st2(u64* p, u64 x, u64 y) {
+    ulonglong2 v;
+    v.x = x;
+    v.y = y;
+    *reinterpret_cast<ulonglong2*>(p) = v;
+}
+
+// grid: x = rows * (N/2/TPB), y = batch
+__global__ __launch_bounds__(TPB) void k_elementwise(EwArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const int mi = g.mod_of[row % g.period];
+    if (mi == LSA_ROW_SKIP) return;
+    const ModDev m = g.mods[mi];
+    const long long off = ((long long)row << g.logn) + x;
+    const long long b = blockIdx.y;
+    const ulonglong2 va = ld2(g.a + b * g.sa + off);
+    u64 r0, r1;
+    if (g.op == EW_NEG) {
+        r0 = neg_mod(va.x, m.q);
+        r1 = neg_mod(va.y, m.q);
+    } else {
+        const ulonglong2 vb = ld2(g.b + b * g.sb + off);
+        if (g.op == EW_ADD) {
+            r0 = add_mod(va.x, vb.x, m.q);
+            r1 = add_mod(va.y, vb.y, m.q);
+        } else if (g.op == EW_SUB) {
+            r0 = sub_mod(va.x, vb.x, m.q);
+            r1 = sub_mod(va.y, vb.y, m.q);
+        } else {
+            r0 = mul_mod(va.x, vb.x, m);
+            r1 = mul_mod(va.y, vb.y, m);
+        }
+    }
+    st2(g.out + b * g.so + off, r0, r1);
+}
+
+static void fill_rowmap(unsigned char* dst, int& period, const RowMap& rm, int nmod) {
+    LSA_REQUIRE(rm.period >= 1 && rm.period <= LSA_MAX_PERIOD, "bad row-map period");
+    period = rm.period;
+    for (int i = 0; i < rm.period; i++) {
+        LSA_REQUIRE(rm.mod_of[i] == LSA_ROW_SKIP || rm.mod_of[i] < nmod, "modulus index out of range");
+        dst[i] = rm.mod_of[i];
+    }
+}
+
+static dim3 ew_grid(const Context& c, int rows, int batch) {
+    LSA_REQUIRE(c.n >= 2 * TPB, "ring degree too small for the elementwise kernels (need N >= 512)");
+    return dim3((unsigned)(rows * (c.n / (2 * TPB))), (unsigned)batch);
+}
+
+void launch_elementwise(Context& c, EwOp op, const u64* a, const u64* b, u64* out, int batch, long long sa, long long sb,
+                        long long so, int rows, const RowMap& rm, hipStream_t s) {
+    if (batch <= 0 || rows <= 0) return;
+    EwArgs g{};
+    g.a = a;
+    g.b = b;
+    g.out = out;
+    g.sa = sa;
+    g.sb = sb;
+    g.so = so;
+    g.mods = c.d_mods;
+    g.rows = rows;
+    g.logn = c.logn;
+    g.op = op;
+    fill_rowmap(g.mod_of, g.period, rm, c.nmod);
+    hipLaunchKernelGGL(k_elementwise, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// tensor product of two degree-1 ciphertexts: d0=a0*b0, d1=a0*b1+a1*b0, d2=a1*b1 (mega_ag_executors_gpu.cu:185,223)
+struct TensorArgs {
+    const u64* a;
+    const u64* b;
+    u64* d;
+    long long sa, sb, sd;
+    const ModDev* mods;
+    int limbs, logn;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+
+__global__ __launch_bounds__(TPB) void k_tensor(TensorArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int limb = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const ModDev m = g.mods[g.mod_of[limb]];
+    const long long b = blockIdx.y;
+    const long long poly = (long long)g.limbs << g.logn;
+    const long long off = ((long long)limb << g.logn) + x;
+    const u64* pa = g.a + b * g.sa + off;
+    const u64* pb = g.b + b * g.sb + off;
+    u64* pd = g.d + b * g.sd + off;
+    const ulonglong2 a0 = ld2(pa), a1 = ld2(pa + poly), b0 = ld2(pb), b1 = ld2(pb + poly);
+    u64 r[3][2];
+    const u64 a0v[2] = {a0.x, a0.y}, a1v[2] = {a1.x, a1.y}, b0v[2] = {b0.x, b0.y}, b1v[2] = {b1.x, b1.y};
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const u64 b0m = mont_mul_lazy(b0v[e], m.r2, m.q, m.qinv);  // to Montgomery form, [0,2q)
+        const u64 b1m = mont_mul_lazy(b1v[e], m.r2, m.q, m.qinv);
+        r[0][e] = mont_mul(a0v[e], b0m, m.q, m.qinv);
+        r[2][e] = mont_mul(a1v[e], b1m, m.q, m.qinv);
+        r[1][e] = add_mod(mont_mul(a0v[e], b1m, m.q, m.qinv), mont_mul(a1v[e], b0m, m.q, m.qinv), m.q);
+    }
+    st2(pd, r[0][0], r[0][1]);
+    st2(pd + poly, r[1][0], r[1][1]);
+    st2(pd + 2 * poly, r[2][0], r[2][1]);
+}
+
+void launch_tensor(Context& c, const u64* a, const u64* b, u64* d, int batch, long long sa, long long sb, long long sd,
+                   int limbs, const RowMap& rm, hipStream_t s) {
+    if (batch <= 0) return;
+    TensorArgs g{};
+    g.a = a;
+    g.b = b;
+    g.d = d;
+    g.sa = sa;
+    g.sb = sb;
+    g.sd = sd;
+    g.mods = c.d_mods;
+    g.limbs = limbs;
+    g.logn = c.logn;
+    LSA_REQUIRE(rm.period == limbs && limbs <= LSA_MAX_PERIOD, "tensor: row map must cover the limbs");
+    int period;
+    fill_rowmap(g.mod_of, period, rm, c.nmod);
+    hipLaunchKernelGGL(k_tensor, ew_grid(c, limbs, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ exact base conversion
+//  y_i = x_i*(S/q_i)^-1 mod q_i ; v = floor(sum double(y_i)/double(q_i)) ;
+// out_j = sum_i y_i*(S/q_i) - v*S mod p_j   [centered: x+floor(S/2) in, -floor(S/2) out]
+struct BaseConvArgs {
+    const BaseConvConsts* k;
+    const ModDev* mods;
+    const u64* src;
+    u64* dst;
+    long long ssrc, sdst;
+    int logn;
+    BaseConvRows rows;
+};
+
+__global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
+    const BaseConvConsts& K = *g.k;
+    const int x = (blockIdx.x * TPB + threadIdx.x) * 2;
+    const long long b = blockIdx.y;
+    const u64* src = g.src + b * g.ssrc + x;
+    u64* dst = g.dst + b * g.sdst + x;
+    const int ns = K.ns, nd = K.nd;
+    u64 y[LSA_BC_MAX_SRC][2];
+    double vf0 = 0.0, vf1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < LSA_BC_MAX_SRC; i++) {
+        if (i < ns) {
+            const ModDev m = g.mods[K.src_mod[i]];
+            ulonglong2 v = ld2(src + ((long long)g.rows.src_row[i] << g.logn));
+            if (K.centered) {
+                v.x = add_mod(v.x, K.half_src[i], m.q);
+                v.y = add_mod(v.y, K.half_src[i], m.q);
+            }
+            y[i][0] = mont_mul(v.x, K.shat_inv_m[i], m.q, m.qinv);
+            y[i][1] = mont_mul(v.y, K.shat_inv_m[i], m.q, m.qinv);
+            const double qf = K.qf[i];
+            vf0 += (double)y[i][0] / qf;   // IEEE division + sequential adds: same float sequence as the oracle
+            vf1 += (double)y[i][1] / qf;
+        }
+    }
+    const int v0 = (int)(u64)vf0, v1 = (int)(u64)vf1;
+    for (int j = 0; j < nd; j++) {
+        const ModDev m = g.mods[K.dst_mod[j]];
+        u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0, r0 = 0, r1 = 0;
+#pragma unroll
+        for (int i = 0; i < LSA_BC_MAX_SRC; i++) {
+            if (i < ns) {
+                const u64 w = K.shat_m[j][i];
+                mac128(h0, l0, y[i][0], w);
+                mac128(h1, l1, y[i][1], w);
+                if ((i & 7) == 7) {  // keep the 128-bit sum below p_j*2^64 (8 products of < 2^61 * p_j)
+                    r0 = add_mod(r0, csub(mont_redc_lazy(h0, l0, m.q, m.qinv), m.q), m.q);
+                    r1 = add_mod(r1, csub(mont_redc_lazy(h1, l1, m.q, m.qinv), m.q), m.q);
+                    h0 = l0 = h1 = l1 = 0;
+                }
+            }
+        }
+        r0 = add_mod(r0, csub(mont_redc_lazy(h0, l0, m.q, m.qinv), m.q), m.q);
+        r1 = add_mod(r1, csub(mont_redc_lazy(h1, l1, m.q, m.qinv), m.q), m.q);
+        r0 = sub_mod(r0, K.vs[j][v0], m.q);
+        r1 = sub_mod(r1, K.vs[j][v1], m.q);
+        if (K.centered) {
+            r0 = sub_mod(r0, K.half_dst[j], m.q);
+            r1 = sub_mod(r1, K.half_dst[j], m.q);
+        }
+        st2(dst + ((long long)g.rows.dst_row[j] << g.logn), r0, r1);
+    }
+}
+
+void launch_baseconv(Context& c, const BaseConvConsts* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
+                     long long ssrc, long long sdst, hipStream_t s) {
+    if (batch <= 0) return;
+    BaseConvArgs g{};
+    g.k = k;
+    g.mods = c.d_mods;
+    g.src = src;
+    g.dst = dst;
+    g.ssrc = ssrc;
+    g.sdst = sdst;
+    g.logn = c.logn;
+    g.rows = rows;
+    hipLaunchKernelGGL(k_baseconv, dim3((unsigned)(c.n / (2 * TPB)), (unsigned)batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ key-switch MAC (K7)
+struct KsMacArgs {
+    const u64* cx;
+    const u64* ext;
+    const u64* key;
+    u64* acc;
+    long long scx, sext, sacc;
+    const ModDev* mods;
+    int logn, L, np, nq, beta, kcomp, klvl;
+};
+
+// grid: x = T * (N/2/TPB), y = batch.  key is in Montgomery form, so sum_d ext_d*key_d needs ONE REDC per output.
+__global__ __launch_bounds__(TPB) void k_ks_mac(KsMacArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int tl = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const int T = g.L + g.np;
+    const int mi = tl < g.L ? tl : g.nq + (tl - g.L);
+    const int kj = tl < g.L ? tl : g.klvl + 1 + (tl - g.L);
+    const ModDev m = g.mods[mi];
+    const long long b = blockIdx.y;
+    const long long N = 1LL << g.logn;
+    u64 h00 = 0, l00 = 0, h01 = 0, l01 = 0, h10 = 0, l10 = 0, h11 = 0, l11 = 0;
+    u64 r00 = 0, r01 = 0, r10 = 0, r11 = 0;
+    for (int d = 0; d < g.beta; d++) {
+        const bool own = tl < g.L && tl >= d * g.np && tl < (d + 1) * g.np;
+        const u64* pe = own ? g.cx + b * g.scx + tl * N + x : g.ext + b * g.sext + ((long long)d * T + tl) * N + x;
+        const ulonglong2 e = ld2(pe);
+        const u64* pk = g.key + ((long long)(d * 2) * g.kcomp + kj) * N + x;
+        const ulonglong2 k0 = ld2(pk), k1 = ld2(pk + (long long)g.kcomp * N);
+        mac128(h00, l00, e.x, k0.x);
+        mac128(h01, l01, e.y, k0.y);
+        mac128(h10, l10, e.x, k1.x);
+        mac128(h11, l11, e.y, k1.y);
+        if ((d & 7) == 7) {  // fold so the 128-bit sum stays below q*2^64 (8 products of < q^2, q < 2^61)
+            r00 = add_mod(r00, csub(mont_redc_lazy(h00, l00, m.q, m.qinv), m.q), m.q);
+            r01 = add_mod(r01, csub(mont_redc_lazy(h01, l01, m.q, m.qinv), m.q), m.q);
+            r10 = add_mod(r10, csub(mont_redc_lazy(h10, l10, m.q, m.qinv), m.q), m.q);
+            r11 = add_mod(r11, csub(mont_redc_lazy(h11, l11, m.q, m.qinv), m.q), m.q);
+            h00 = l00 = h01 = l01 = h10 = l10 = h11 = l11 = 0;
+        }
+    }
+    r00 = add_mod(r00, csub(mont_redc_lazy(h00, l00, m.q, m.qinv), m.q), m.q);
+    r01 = add_mod(r01, csub(mont_redc_lazy(h01, l01, m.q, m.qinv), m.q), m.q);
+    r10 = add_mod(r10, csub(mont_redc_lazy(h10, l10, m.q, m.qinv), m.q), m.q);
+    r11 = add_mod(r11, csub(mont_redc_lazy(h11, l11, m.q, m.qinv), m.q), m.q);
+    u64* pa = g.acc + b * g.sacc + tl * N + x;
+    st2(pa, r00, r01);
+    st2(pa + (long long)T * N, r10, r11);
+}
+
+void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext, const Key& key,
+                   u64* acc, long long sacc, int batch, hipStream_t s) {
+    if (batch <= 0) return;
+    KsMacArgs g{};
+    g.cx = cx;
+    g.ext = ext;
+    g.key = key.data;
+    g.acc = acc;
+    g.scx = scx;
+    g.sext = sext;
+    g.sacc = sacc;
+    g.mods = c.d_mods;
+    g.logn = c.logn;
+    g.L = level + 1;
+    g.np = c.np;
+    g.nq = c.nq;
+    g.beta = (g.L + c.np - 1) / c.np;
+    g.klvl = key.level;
+    g.kcomp = key.level + 1 + c.np;
+    LSA_REQUIRE(key.level >= level, "key-switch key exported at a lower level than the ciphertext");
+    hipLaunchKernelGGL(k_ks_mac, ew_grid(c, g.L + c.np, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ (a-b)*k, a*k, ModDown tail
+struct SubMulArgs {
+    const u64* a;
+    const u64* b;     // may be null: out = a*k
+    const u64* base;  // may be null: else out += base
+    const u64* kvec;  // per row-class constant, Montgomery form, indexed like mod_of
+    u64* out;
+    long long sa, sb, sbase, so;
+    int a_rpp, b_rpp, base_rpp, out_rpp;  // rows per polynomial of each operand (row = poly*rpp + limb)
+    int base_polys;                       // base is added to polynomials [0, base_polys)
+    int limbs, logn;
+    const ModDev* mods;
+    unsigned char mod_of[LSA_MAX_PERIOD];  // per limb
+};
+
+// grid: x = polys*limbs*(N/2/TPB), y = batch
+__global__ __launch_bounds__(TPB) void k_sub_mul(SubMulArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int pl = blockIdx.x / chunks;
+    const int poly = pl / g.limbs, limb = pl % g.limbs;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const ModDev m = g.mods[g.mod_of[limb]];
+    const u64 k = g.kvec[limb];
+    const long long b = blockIdx.y;
+    ulonglong2 va = ld2(g.a + b * g.sa + (((long long)poly * g.a_rpp + limb) << g.logn) + x);
+    if (g.b) {
+        const ulonglong2 vb = ld2(g.b + b * g.sb + (((long long)poly * g.b_rpp + limb) << g.logn) + x);
+        va.x = sub_mod(va.x, vb.x, m.q);
+        va.y = sub_mod(va.y, vb.y, m.q);
+    }
+    u64 r0 = mont_mul(va.x, k, m.q, m.qinv), r1 = mont_mul(va.y, k, m.q, m.qinv);
+    if (g.base && poly < g.base_polys) {
+        const ulonglong2 vc = ld2(g.base + b * g.sbase + (((long long)poly * g.base_rpp + limb) << g.logn) + x);
+        r0 = add_mod(r0, vc.x, m.q);
+        r1 = add_mod(r1, vc.y, m.q);
+    }
+    st2(g.out + b * g.so + (((long long)poly * g.out_rpp + limb) << g.logn) + x, r0, r1);
+}
+
+void launch_sub_mul_general(Context& c, int polys, int limbs, const unsigned char* limb_mod, const u64* kvec,
+                                   const u64* a, long long sa, int a_rpp, const u64* b, long long sb, int b_rpp,
+                                   const u64* base, long long sbase, int base_rpp, int base_polys, u64* out,
+                                   long long so, int out_rpp, int batch, hipStream_t s) {
+    if (batch <= 0) return;
+    SubMulArgs g{};
+    g.a = a;
+    g.b = b;
+    g.base = base;
+    g.kvec = kvec;
+    g.out = out;
+    g.sa = sa;
+    g.sb = sb;
+    g.sbase = sbase;
+    g.so = so;
+    g.a_rpp = a_rpp;
+    g.b_rpp = b_rpp;
+    g.base_rpp = base_rpp;
+    g.base_polys = base_polys;
+    g.out_rpp = out_rpp;
+    g.limbs = limbs;
+    g.logn = c.logn;
+    g.mods = c.d_mods;
+    LSA_REQUIRE(limbs <= LSA_MAX_PERIOD, "too many limbs");
+    for (int i = 0; i < limbs; i++) g.mod_of[i] = limb_mod[i];
+    hipLaunchKernelGGL(k_sub_mul, ew_grid(c, polys * limbs, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+void launch_moddown_final(Context& c, int level, const u64* acc, long long sacc, int acc_rpp, const u64* conv,
+                          long long sconv, const u64* base, long long sbase, int base_rpp, int base_polys, u64* out,
+                          long long sout, int batch, hipStream_t s) {
+    const int L = level + 1;
+    std::vector<int> mods(L);
+    std::vector<u64> pinv(L);
+    unsigned char lm[LSA_MAX_PERIOD];
+    for (int i = 0; i < L; i++) {
+        mods[i] = i;
+        lm[i] = (unsigned char)i;
+        u64 q = c.T.mod[i], pr = 1;
+        for (int l = 0; l < c.np; l++) pr = mul_mod_host(pr, c.T.mod[c.p_mod(l)] % q, q);
+        pinv[i] = inv_mod(pr, q);
+    }
+    const u64* kv = c.const_vec("pinv" + std::to_string(L), mods, pinv);
+    launch_sub_mul_general(c, 2, L, lm, kv, acc, sacc, acc_rpp, conv, sconv, L, base, sbase, base_rpp, base_polys, out,
+                           sout, L, batch, s);
+}
+
+void launch_sub_mul_const(Context& c, const u64* a, long long sa, const u64* b, long long sb, const u64* kvec, u64* out,
+                          long long so, int rows, const RowMap& rm, int batch, hipStream_t s) {
+    launch_sub_mul_general(c, 1, rows, rm.mod_of, kvec, a, sa, rows, b, sb, rows, nullptr, 0, 0, 0, out, so, rows, batch,
+                           s);
+}
+
+void launch_mul_const(Context& c, const u64* a, long long sa, const u64* kvec, u64* out, long long so, int rows,
+                      const RowMap& rm, int batch, hipStream_t s) {
+    launch_sub_mul_general(c, 1, rows, rm.mod_of, kvec, a, sa, rows, nullptr, 0, 0, nullptr, 0, 0, 0, out, so, rows,
+                           batch, s);
+}
+
+// ------------------------------------------------------------------------------------------------ rescale (K9)
+struct RescaleArgs {
+    const u64* last;  // [batch][polys][N] coefficient-domain last limb
+    u64* tmp;         // [batch][polys][level][N]
+    long long slast, stmp;
+    const ModDev* mods;
+    int level, polys, logn;
+};
+
+// tmp[p][i] = ((last + h) mod q_l) mod q_i - (h mod q_i),  h = (q_l-1)/2     (divide-and-round, centred remainder)
+__global__ __launch_bounds__(TPB) void k_rescale_prep(RescaleArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int pl = blockIdx.x / chunks;
+    const int poly = pl / g.level, limb = pl % g.level;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const long long b = blockIdx.y;
+    const ModDev ml = g.mods[g.level], mi = g.mods[limb];
+    const u64 h = (ml.q - 1) >> 1;
+    const u64 hq = reduce_u64(h, mi);
+    const ulonglong2 v = ld2(g.last + b * g.slast + ((long long)poly << g.logn) + x);
+    const u64 r0 = sub_mod(reduce_u64(add_mod(v.x, h, ml.q), mi), hq, mi.q);
+    const u64 r1 = sub_mod(reduce_u64(add_mod(v.y, h, ml.q), mi), hq, mi.q);
+    st2(g.tmp + b * g.stmp + (((long long)poly * g.level + limb) << g.logn) + x, r0, r1);
+}
+
+void launch_rescale_prep(Context& c, int level, int polys, const u64* last, long long slast, u64* tmp, long long stmp,
+                         int batch, hipStream_t s) {
+    if (batch <= 0) return;
+    RescaleArgs g{};
+    g.last = last;
+    g.tmp = tmp;
+    g.slast = slast;
+    g.stmp = stmp;
+    g.mods = c.d_mods;
+    g.level = level;
+    g.polys = polys;
+    g.logn = c.logn;
+    hipLaunchKernelGGL(k_rescale_prep, ew_grid(c, polys * level, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+void launch_rescale_final(Context& c, int level, int polys, const u64* in, long long sin, const u64* tmp, long long stmp,
+                          u64* out, long long sout, int batch, hipStream_t s) {
+    std::vector<int> mods(level);
+    std::vector<u64> qlinv(level);
+    unsigned char lm[LSA_MAX_PERIOD];
+    const u64 ql = c.T.mod[level];
+    for (int i = 0; i < level; i++) {
+        mods[i] = i;
+        lm[i] = (unsigned char)i;
+        qlinv[i] = inv_mod(ql % c.T.mod[i], c.T.mod[i]);
+    }
+    const u64* kv = c.const_vec("qlinv" + std::to_string(level), mods, qlinv);
+    launch_sub_mul_general(c, polys, level, lm, kv, in, sin, level + 1, tmp, stmp, level, nullptr, 0, 0, 0, out, sout,
+                           level, batch, s);
+}
+
+// ------------------------------------------------------------------------------------------------ automorphisms (K10)
+struct PermArgs {
+    const u32* perm;
+    const u64* in;
+    u64* out;
+    long long sin, sout;
+    const ModDev* mods;
+    int rows, logn, with_sign, period;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+
+// out[row][i] = (+/-) in[row][perm[i] & 0x7fffffff]; sign bit 31 negates (coefficient-domain automorphism)
+__global__ __launch_bounds__(TPB) void k_permute(PermArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const long long b = blockIdx.y;
+    const u64* in = g.in + b * g.sin + ((long long)row << g.logn);
+    const uint2 p = *reinterpret_cast<const uint2*>(g.perm + x);
+    u64 r0 = in[p.x & 0x7fffffffu], r1 = in[p.y & 0x7fffffffu];
+    if (g.with_sign) {
+        const u64 q = g.mods[g.mod_of[row % g.period]].q;
+        if (p.x >> 31) r0 = neg_mod(r0, q);
+        if (p.y >> 31) r1 = neg_mod(r1, q);
+    }
+    st2(g.out + b * g.sout + ((long long)row << g.logn) + x, r0, r1);
+}
+
+void launch_permute_ntt(Context& c, const u32* perm, const u64* in, long long sin, u64* out, long long sout, int rows,
+                        int batch, hipStream_t s) {
+    if (batch <= 0) return;
+    PermArgs g{};
+    g.perm = perm;
+    g.in = in;
+    g.out = out;
+    g.sin = sin;
+    g.sout = sout;
+    g.mods = c.d_mods;
+    g.rows = rows;
+    g.logn = c.logn;
+    g.with_sign = 0;
+    g.period = 1;
+    hipLaunchKernelGGL(k_permute, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+void launch_permute_coeff(Context& c, const u32* perm, const u64* in, long long sin, u64* out, long long sout, int rows,
+                          const RowMap& rm, int batch, hipStream_t s) {
+    if (batch <= 0) return;
+    PermArgs g{};
+    g.perm = perm;
+    g.in = in;
+    g.out = out;
+    g.sin = sin;
+    g.sout = sout;
+    g.mods = c.d_mods;
+    g.rows = rows;
+    g.logn = c.logn;
+    g.with_sign = 1;
+    fill_rowmap(g.mod_of, g.period, rm, c.nmod);
+    hipLaunchKernelGGL(k_permute, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ row copy (K12) / to-Montgomery
+struct CopyRowsArgs {
+    const u64* in;
+    u64* out;
+    long long sin, sout;
+    int rows, logn;
+    short src_row[LSA_MAX_PERIOD];
+};
+
+__global__ __launch_bounds__(TPB) void k_copy_rows(CopyRowsArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const long long b = blockIdx.y;
+    const ulonglong2 v = ld2(g.in + b * g.sin + ((long long)g.src_row[row] << g.logn) + x);
+    st2(g.out + b * g.sout + ((long long)row << g.logn) + x, v.x, v.y);
+}
+
+void launch_copy_rows(Context& c, const u64* in, long long sin, u64* out, long long sout, int rows, const int* src_row,
+                      int batch, hipStream_t s) {
+    if (batch <= 0 || rows <= 0) return;
+    LSA_REQUIRE(rows <= LSA_MAX_PERIOD, "copy_rows: too many rows");
+    CopyRowsArgs g{};
+    g.in = in;
+    g.out = out;
+    g.sin = sin;
+    g.sout = sout;
+    g.rows = rows;
+    g.logn = c.logn;
+    for (int i = 0; i < rows; i++) g.src_row[i] = (short)src_row[i];
+    hipLaunchKernelGGL(k_copy_rows, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+struct ToMontArgs {
+    u64* data;
+    const ModDev* mods;
+    int logn, period;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+
+__global__ __launch_bounds__(TPB) void k_to_mont(ToMontArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const ModDev m = g.mods[g.mod_of[row % g.period]];
+    u64* p = g.data + ((long long)row << g.logn) + x;
+    const ulonglong2 v = ld2(p);
+    st2(p, mont_mul(v.x, m.r2, m.q, m.qinv), mont_mul(v.y, m.r2, m.q, m.qinv));
+}
+
+void launch_to_mont(Context& c, u64* data, int rows, const RowMap& rm, hipStream_t s) {
+    if (rows <= 0) return;
+    ToMontArgs g{};
+    g.data = data;
+    g.mods = c.d_mods;
+    g.logn = c.logn;
+    fill_rowmap(g.mod_of, g.period, rm, c.nmod);
+    hipLaunchKernelGGL(k_to_mont, ew_grid(c, rows, 1), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ probes (ceilings for DESIGN.md)
+__global__ __launch_bounds__(TPB) void k_probe_copy(u64* dst, const u64* src, size_t n2) {
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n2; i += (size_t)gridDim.x * TPB) {
+        const ulonglong2 v = ld2(src + 2 * i);
+        st2(dst + 2 * i, v.x, v.y);
+    }
+}
+void launch_probe_copy(u64* dst, const u64* src, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_probe_copy, dim3(256 * 8), dim3(TPB), 0, s, dst, src, n / 2);
+    LSA_HIP(hipGetLastError());
+}
+
+// dependent chains of Montgomery multiplies, 4 independent chains per lane: measures the 64-bit modmul issue ceiling
+__global__ __launch_bounds__(TPB) void k_probe_mulhi(u64* buf, size_t n, int iters) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i * 4 + 3 >= n) return;
+    const u64 q = 0x1FFFFFFFFFE00001ull, qinv = 1;  // constants irrelevant for timing
+    u64 a = buf[4 * i], b = buf[4 * i + 1], c = buf[4 * i + 2], d = buf[4 * i + 3];
+    const u64 w = a | 1;
+    for (int it = 0; it < iters; it++) {
+        a = mont_mul_lazy(a, w, q, qinv + it);
+        b = mont_mul_lazy(b, w, q, qinv + it);
+        c = mont_mul_lazy(c, w, q, qinv + it);
+        d = mont_mul_lazy(d, w, q, qinv + it);
+    }
+    buf[4 * i] = a;
+    buf[4 * i + 1] = b;
+    buf[4 * i + 2] = c;
+    buf[4 * i + 3] = d;
+}
+void launch_probe_mulhi(u64* buf, size_t n, int iters, hipStream_t s) {
+    const size_t threads = n / 4;
+    hipLaunchKernelGGL(k_probe_mulhi, dim3((unsigned)((threads + TPB - 1) / TPB)), dim3(TPB), 0, s, buf, n, iters);
+    LSA_HIP(hipGetLastError());
+}
+
+}  // namespace lsa

@@ -1,0 +1,160 @@
+// lsa_internal.h — context, device tables, workspace and launcher declarations (host side, C++).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/lattisense_amd.h"
+#include "ntt_plan.h"
+#include "tables.h"
+
+namespace lsa {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& m);
+
+#define LSA_HIP(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            throw lsa::Error(_e == hipErrorNoDevice || _e == hipErrorInvalidDevice ? LSA_ERR_NO_DEVICE    \
+                                                                                   : LSA_ERR_HIP,        \
+                             std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+    } while (0)
+
+#define LSA_REQUIRE(cond, msg)                                   \
+    do {                                                         \
+        if (!(cond)) throw lsa::Error(LSA_ERR_ARG, (msg));       \
+    } while (0)
+
+// ---------------------------------------------------------------- exact RNS base conversion plan (device constants)
+#define LSA_BC_MAX_SRC 16
+#define LSA_BC_MAX_DST 64
+
+struct BaseConvConsts {
+    int ns, nd, centered;
+    int src_mod[LSA_BC_MAX_SRC];
+    int dst_mod[LSA_BC_MAX_DST];
+    u64 shat_inv_m[LSA_BC_MAX_SRC];                 // (S/q_i)^-1 mod q_i, Montgomery form
+    u64 half_src[LSA_BC_MAX_SRC];                   // floor(S/2) mod q_i
+    double qf[LSA_BC_MAX_SRC];                      // (double) q_i
+    u64 shat_m[LSA_BC_MAX_DST][LSA_BC_MAX_SRC];     // (S/q_i) mod p_j, Montgomery form
+    u64 vs[LSA_BC_MAX_DST][LSA_BC_MAX_SRC + 1];     // v*S mod p_j, v = 0..ns
+    u64 half_dst[LSA_BC_MAX_DST];                   // floor(S/2) mod p_j
+};
+
+struct Key {
+    u64* data = nullptr;   // device, compact order [beta][2][klvl+1+np][N], NTT domain, MONTGOMERY form
+    int level = 0;
+    bool owned = true;
+};
+
+struct Context {
+    int algo, n, logn, nq, np, nmul, nmod, device;
+    u64 t;
+    HostTables T;
+    NttPlan plan;
+    ModDev* d_mods = nullptr;
+    u64* d_psi = nullptr;
+    u64* d_psiinv = nullptr;
+    u64* d_scale = nullptr;
+    int tile_batch = 0;
+
+    std::mutex mu;
+    std::map<std::string, BaseConvConsts*> bconv;   // device copies, keyed by "c|src..|dst.."
+    std::map<u64, u32*> perm_ntt;                   // galois element -> device gather table (NTT domain)
+    std::map<u64, u32*> perm_coeff;                 // galois element -> device scatter table with sign bit
+    std::map<std::string, u64*> consts;             // misc per-level device constant vectors
+
+    // workspace arena: grows on demand, reused across calls (single in-flight operator per context)
+    u64* ws = nullptr;
+    size_t ws_words = 0;
+
+    Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_, u64 t_, int device_);
+    ~Context();
+    void use_device() const { LSA_HIP(hipSetDevice(device)); }
+    u64* workspace(size_t words, hipStream_t s);
+    u64* ws2 = nullptr;   // second arena: operator-to-operator intermediates of composed entry points
+    size_t ws2_words = 0;
+    u64* workspace2(size_t words, hipStream_t s);
+    int p_mod(int i) const { return nq + i; }
+    int aux_mod(int i) const { return nq + np + i; }
+    const BaseConvConsts* baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered);
+    const u32* ntt_perm(u64 g);
+    const u32* coeff_perm(u64 g);
+    // per-modulus constant vector on device, Montgomery form, built by `gen(mod_index)`
+    const u64* const_vec(const std::string& name, const std::vector<int>& mods, const std::vector<u64>& plain_vals);
+};
+
+// ---------------------------------------------------------------- launchers (kernels.hip)
+struct RowMap {   // rows of a batch item -> modulus index (0xFF = skip)
+    int period;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+
+void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch_stride, int rows, const RowMap& rm,
+                bool inverse, hipStream_t s);
+void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
+                const RowMap& rm, bool inverse, hipStream_t s);
+
+// limb-wise binary/unary ops on [batch][rows][N]; row r uses modulus rm.mod_of[r % period]
+enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MUL = 3 };
+void launch_elementwise(Context& c, EwOp op, const u64* a, const u64* b, u64* out, int batch, long long sa,
+                        long long sb, long long so, int rows, const RowMap& rm, hipStream_t s);
+// CKKS/BFV tensor: a,b [2][T][N] -> d [3][T][N]; limb i uses modulus rm.mod_of[i]
+void launch_tensor(Context& c, const u64* a, const u64* b, u64* d, int batch, long long sa, long long sb, long long sd,
+                   int limbs, const RowMap& rm, hipStream_t s);
+// exact base conversion: src limbs at rows src_row[i] of the source item, dst limbs at rows dst_row[j] of the dest item
+struct BaseConvRows {
+    int src_row[LSA_BC_MAX_SRC];
+    int dst_row[LSA_BC_MAX_DST];
+};
+void launch_baseconv(Context& c, const BaseConvConsts* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
+                     long long ssrc, long long sdst, hipStream_t s);
+// key-switch inner product: acc[h][tl] = sum_d ext(d,tl) * key[d][h][tl];  ext(d,tl) = cx[tl] when tl is in digit d
+void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext,
+                   const Key& key, u64* acc, long long sacc, int batch, hipStream_t s);
+// out[h][i] = base[h][i] + (acc[h][i] - conv[h][i]) * Pinv_i       (base may be null)
+void launch_moddown_final(Context& c, int level, const u64* acc, long long sacc, int acc_rows_per_poly, const u64* conv,
+                          long long sconv, const u64* base, long long sbase, int base_rows_per_poly, int base_polys,
+                          u64* out, long long sout, int batch, hipStream_t s);
+// out[p][i] = base[p][i] + (a[p][i] - b[p][i]) * kvec[i]; row of operand X = p*X_rpp + i; b/base optional
+void launch_sub_mul_general(Context& c, int polys, int limbs, const unsigned char* limb_mod, const u64* kvec,
+                            const u64* a, long long sa, int a_rpp, const u64* b, long long sb, int b_rpp,
+                            const u64* base, long long sbase, int base_rpp, int base_polys, u64* out, long long so,
+                            int out_rpp, int batch, hipStream_t s);
+// rescale helpers (divide-and-round by the last modulus of `level`)
+void launch_rescale_prep(Context& c, int level, int polys, const u64* last, long long slast, u64* tmp, long long stmp,
+                         int batch, hipStream_t s);
+void launch_rescale_final(Context& c, int level, int polys, const u64* in, long long sin, const u64* tmp, long long stmp,
+                          u64* out, long long sout, int batch, hipStream_t s);
+// gather rows: out[r][i] = in[r][perm[i]] (NTT domain automorphism) ; scatter with sign for coefficient domain
+void launch_permute_ntt(Context& c, const u32* perm, const u64* in, long long sin, u64* out, long long sout, int rows,
+                        int batch, hipStream_t s);
+void launch_permute_coeff(Context& c, const u32* perm, const u64* in, long long sin, u64* out, long long sout, int rows,
+                          const RowMap& rm, int batch, hipStream_t s);
+// strided row copy: out[b][r] = in[b][src_row[r]]
+void launch_copy_rows(Context& c, const u64* in, long long sin, u64* out, long long sout, int rows, const int* src_row,
+                      int batch, hipStream_t s);
+void launch_to_mont(Context& c, u64* data, int rows, const RowMap& rm, hipStream_t s);
+// out = (a - b) * k_i  with per-row constant (Montgomery form) ; out = a * k_i
+void launch_sub_mul_const(Context& c, const u64* a, long long sa, const u64* b, long long sb, const u64* kvec, u64* out,
+                          long long so, int rows, const RowMap& rm, int batch, hipStream_t s);
+void launch_mul_const(Context& c, const u64* a, long long sa, const u64* kvec, u64* out, long long so, int rows,
+                      const RowMap& rm, int batch, hipStream_t s);
+void launch_probe_copy(u64* dst, const u64* src, size_t n, hipStream_t s);
+void launch_probe_mulhi(u64* buf, size_t n, int iters, hipStream_t s);
+
+// ---------------------------------------------------------------- operator pipelines (ops.hip)
+const std::string& last_error();
+
+}  // namespace lsa

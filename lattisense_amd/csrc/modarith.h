@@ -1,0 +1,68 @@
+// modarith.h — 64-bit modular arithmetic for gfx950 (no native 64x64->128: built from v_mad_u64_u32 / v_mul_hi_u32
+// sequences the compiler emits for __umul64hi).  Montgomery radix 2^64, primes up to 61 bits so that 4q < 2^63 and
+// Harvey-style lazy butterflies stay inside one 64-bit word.
+//
+// The same functions compile for the host (unsigned __int128) so the kernel phase functions can be replayed
+// thread-by-thread on the CPU (LSA_EMULATE, tests/test_emulate_ntt.py) — that is a debugging aid for the kernel's
+// own indexing, not a product fallback: the library refuses to run without a GPU.
+#pragma once
+#include <stdint.h>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+#if defined(LSA_EMULATE)
+#define LSA_HD inline
+#define LSA_D inline
+#else
+#include <hip/hip_runtime.h>
+#define LSA_HD __host__ __device__ __forceinline__
+#define LSA_D __device__ __forceinline__
+#endif
+
+struct ModDev {
+    u64 q;      // modulus
+    u64 qinv;   // q^-1 mod 2^64   (Lattigo MRedParams convention: r = hi - mulhi(lo*qinv, q))
+    u64 r2;     // 2^128 mod q     (to-Montgomery constant)
+    u64 r1;     // 2^64 mod q      (Montgomery one)
+};
+
+LSA_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// REDC of the 128-bit value (hi,lo) < q*2^64  ->  [0, 2q)   ("lazy": caller reduces when it must)
+LSA_HD u64 mont_redc_lazy(u64 hi, u64 lo, u64 q, u64 qinv) {
+    u64 m = lo * qinv;
+    u64 t = mulhi64(m, q);
+    return hi - t + q;
+}
+// a*b*2^-64 mod q in [0,2q); requires a*b < q*2^64 (e.g. a < 2^63, b < q)
+LSA_HD u64 mont_mul_lazy(u64 a, u64 b, u64 q, u64 qinv) {
+    return mont_redc_lazy(mulhi64(a, b), a * b, q, qinv);
+}
+LSA_HD u64 csub(u64 a, u64 q) { return a >= q ? a - q : a; }
+// a*b*2^-64 mod q in [0,q)
+LSA_HD u64 mont_mul(u64 a, u64 b, u64 q, u64 qinv) { return csub(mont_mul_lazy(a, b, q, qinv), q); }
+// plain a*b mod q for a,b in [0,q): two REDCs (a*b*R^-1, then *R^2*R^-1)
+LSA_HD u64 mul_mod(u64 a, u64 b, const ModDev& m) {
+    return mont_mul(mont_mul_lazy(a, b, m.q, m.qinv), m.r2, m.q, m.qinv);
+}
+LSA_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
+LSA_HD u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+LSA_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// 128-bit accumulate helper: (hi,lo) += a*b
+LSA_HD void mac128(u64& hi, u64& lo, u64 a, u64 b) {
+    u64 pl = a * b, ph = mulhi64(a, b);
+    lo += pl;
+    hi += ph + (lo < pl ? 1 : 0);
+}
+// x mod q for arbitrary 64-bit x and q > 2^32-ish chain primes of any size: via Montgomery (x*R^-1 then *R^2)
+LSA_HD u64 reduce_u64(u64 x, const ModDev& m) {
+    return mont_mul(mont_redc_lazy(0, x, m.q, m.qinv), m.r2, m.q, m.qinv);
+}

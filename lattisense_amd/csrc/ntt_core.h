@@ -1,0 +1,205 @@
+// ntt_core.h — batched negacyclic NTT / INTT passes over 64-bit RNS limbs for gfx950.
+//
+// Replaces the NTT kernels of the absent HEonGPU library behind every call site of
+// mega_ag_runners/gpu/mega_ag_executors_gpu.cu:185-289.  Ordering and roots follow the ABI's
+// canonical (Lattigo) convention: forward = Cooley-Tukey, natural in -> bit-reversed out, twiddle psi^{brv(m+i)};
+// inverse = Gentleman-Sande with N^-1 folded into the last stage.
+//
+// Structure (MI355X-first, not a port of a CUDA warp-shuffle NTT):
+//   * a limb of N = 2^logn points is transformed in one or two PASSES; a pass covers `mu` consecutive radix-2 stages
+//     [s_lo, s_lo+mu) on a TILE of 2^tau points staged through LDS (<= 34 KiB so 4 workgroups share a CU's 160 KiB
+//     and their HBM loads / butterflies / stores overlap);
+//   * inside a pass every thread owns radix-2^rho groups (rho <= 4): 16 points live in VGPRs for 4 stages, so a point
+//     crosses LDS once per 4 stages instead of once per stage;
+//   * all global accesses are 16 B/lane and contiguous per wave (pass A gathers >=128 B column segments);
+//   * LDS layout pads one 8-byte word per 16 so that both the stride-16 and the unit-stride sub-passes are
+//     conflict-free for ds_read_b64/ds_write_b64 (bank = (addr/4) mod 64, lane groups of 32);
+//   * blockIdx -> (limb, tile, batch) with batch fastest: co-resident workgroups share one prime's twiddle slice, which
+//     therefore stays in L1/L2 (twiddles are excluded from the algorithmic byte count for exactly that reason).
+//
+// Values are kept lazily in [0,4q) inside a pass (q < 2^61) and fully reduced on the final store.
+#pragma once
+#include "modarith.h"
+
+#define LSA_NTT_THREADS 256
+#define LSA_MAX_PERIOD 192
+#define LSA_ROW_SKIP 0xFF
+
+struct NttPassArgs {
+    const u64* src;       // batch base (may equal dst)
+    u64* dst;
+    long long src_stride;    // elements between consecutive batch items of src
+    long long dst_stride;    // ... of dst
+    int batch;            // number of batch items
+    int rows;             // limb-polynomials per batch item, each N contiguous elements
+    const ModDev* mods;   // [nmod]
+    const u64* tw;        // [nmod][N] Montgomery-form psi^{brv(x)} (forward) or psi^{-brv(x)} (inverse)
+    const u64* scale;     // [nmod][2] inverse only: {N^-1 * R, psiinv[1] * N^-1 * R}
+    int logn, s_lo, mu, lambda, tau;
+    int inverse;          // 0 forward, 1 inverse
+    int apply_scale;      // inverse: this pass contains global stage 0 -> fold N^-1
+    int final_reduce;     // store fully reduced [0,q)
+    int period;           // row r uses modulus mod_of[r % period]
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+
+LSA_HD int lds_addr(int l) { return l + (l >> 4); }
+LSA_HD int lds_words(int tau) { return (1 << tau) + (1 << (tau - 4)) + 16; }
+
+struct NttBlockCtx {
+    long long base_src;   // element offset of this (batch,row) limb in src
+    long long base_dst;   // ... in dst
+    int tile;         // tile index inside the limb
+    int mod;          // modulus index
+};
+
+LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
+    NttBlockCtx c;
+    int tiles = 1 << (a.logn - a.tau);
+    int b = (int)(bid % a.batch);
+    long long rt = bid / a.batch;
+    c.tile = (int)(rt % tiles);
+    int row = (int)(rt / tiles);
+    c.base_src = (long long)b * a.src_stride + ((long long)row << a.logn);
+    c.base_dst = (long long)b * a.dst_stride + ((long long)row << a.logn);
+    c.mod = a.mod_of[row % a.period];
+    return c;
+}
+
+// local tile index l -> element index inside the limb
+LSA_HD int ntt_global_index(const NttPassArgs& a, int tile, int l) {
+    if (a.lambda == 0) return (tile << a.tau) + l;  // contiguous tile
+    int lo_bits = a.logn - a.s_lo - a.mu;           // >= lambda
+    int C = 1 << a.lambda;
+    int blocks_per_hi = 1 << (lo_bits - a.lambda);
+    int hi = tile / blocks_per_hi, lob = tile % blocks_per_hi;
+    int r = l >> a.lambda, c = l & (C - 1);
+    return (hi << (a.logn - a.s_lo)) + (r << lo_bits) + lob * C + c;
+}
+
+// "hi" index (the s_lo leading bits of the element index) of local element l
+LSA_HD int ntt_hi_index(const NttPassArgs& a, int tile, int l) {
+    if (a.lambda == 0) return ((tile << a.tau) + l) >> a.mu;
+    int lo_bits = a.logn - a.s_lo - a.mu;
+    return tile >> (lo_bits - a.lambda);
+}
+
+// phase 0: global -> LDS (2 elements = 16 B per lane per step)
+LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
+    const u64* g = a.src + bc.base_src;
+    int half = 1 << (a.tau - 1);
+    for (int i = tid; i < half; i += LSA_NTT_THREADS) {
+        int l = 2 * i;
+        int x = ntt_global_index(a, bc.tile, l);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g + x);
+        lds[lds_addr(l)] = v.x;
+        lds[lds_addr(l + 1)] = v.y;
+#else
+        lds[lds_addr(l)] = g[x];
+        lds[lds_addr(l + 1)] = g[x + 1];
+#endif
+    }
+}
+
+// final phase: LDS -> global
+LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64* lds) {
+    u64* g = a.dst + bc.base_dst;
+    const u64 q = a.mods[bc.mod].q;
+    int half = 1 << (a.tau - 1);
+    for (int i = tid; i < half; i += LSA_NTT_THREADS) {
+        int l = 2 * i;
+        int x = ntt_global_index(a, bc.tile, l);
+        u64 v0 = lds[lds_addr(l)], v1 = lds[lds_addr(l + 1)];
+        if (a.final_reduce) {
+            v0 = csub(csub(v0, 2 * q), q);
+            v1 = csub(csub(v1, 2 * q), q);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        ulonglong2 v;
+        v.x = v0;
+        v.y = v1;
+        *reinterpret_cast<ulonglong2*>(g + x) = v;
+#else
+        g[x] = v0;
+        g[x + 1] = v1;
+#endif
+    }
+}
+
+// One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass.
+template <int RHO>
+LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
+    constexpr int E = 1 << RHO;
+    const ModDev md = a.mods[bc.mod];
+    const u64 q = md.q, qinv = md.qinv, q2 = 2 * md.q;
+    const u64* tw = a.tw + ((long long)bc.mod << a.logn);
+    const int beta0 = a.lambda + a.mu - sig0 - RHO;  // lowest active bit of this sub-pass in l
+    const int ngroups = 1 << (a.tau - RHO);
+    for (int gid = tid; gid < ngroups; gid += LSA_NTT_THREADS) {
+        int lbase = ((gid >> beta0) << (beta0 + RHO)) | (gid & ((1 << beta0) - 1));
+        u64 v[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) v[e] = lds[lds_addr(lbase + (e << beta0))];
+        // G = H * 2^sig0 + r_high ; r = (l >> lambda) & (2^mu - 1)
+        int r = (lbase >> a.lambda) & ((1 << a.mu) - 1);
+        int H = ntt_hi_index(a, bc.tile, lbase);
+        int G = (H << sig0) + (r >> (a.mu - sig0));
+        if (!a.inverse) {
+#pragma unroll
+            for (int j = 0; j < RHO; j++) {
+                const int half = E >> (j + 1);
+                const int s = a.s_lo + sig0 + j;
+                const u64* twj = tw + (1 << s) + ((long long)G << j);
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if ((e & half) == 0) {
+                        u64 w = twj[e >> (RHO - j)];
+                        u64 U = csub(v[e], q2);
+                        u64 T = mont_mul_lazy(v[e + half], w, q, qinv);
+                        v[e] = U + T;
+                        v[e + half] = U + q2 - T;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = RHO - 1; j >= 0; j--) {
+                const int half = E >> (j + 1);
+                const int s = a.s_lo + sig0 + j;
+                const u64* twj = tw + (1 << s) + ((long long)G << j);
+                const bool last = a.apply_scale && s == 0;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if ((e & half) == 0) {
+                        u64 w = last ? a.scale[2 * bc.mod + 1] : twj[e >> (RHO - j)];
+                        u64 U = v[e], V = v[e + half];   // both in [0,2q)
+                        u64 S = U + V;                    // [0,4q)
+                        u64 D = U + q2 - V;               // (0,4q)
+                        v[e] = last ? mont_mul_lazy(S, a.scale[2 * bc.mod], q, qinv) : csub(S, q2);
+                        v[e + half] = mont_mul_lazy(D, w, q, qinv);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) lds[lds_addr(lbase + (e << beta0))] = v[e];
+    }
+}
+
+// sub-pass plan: split mu stages into ceil(mu/4) nearly equal radix groups (each <= 4)
+LSA_HD int ntt_plan(int mu, int* rho /*[4]*/) {
+    int n = (mu + 3) / 4;
+    int base = mu / n, extra = mu % n;
+    for (int i = 0; i < n; i++) rho[i] = base + (i < extra ? 1 : 0);
+    return n;
+}
+
+LSA_HD void ntt_phase_sub_dyn(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
+    switch (rho) {
+        case 1: ntt_phase_sub<1>(a, bc, tid, lds, sig0); break;
+        case 2: ntt_phase_sub<2>(a, bc, tid, lds, sig0); break;
+        case 3: ntt_phase_sub<3>(a, bc, tid, lds, sig0); break;
+        default: ntt_phase_sub<4>(a, bc, tid, lds, sig0); break;
+    }
+}

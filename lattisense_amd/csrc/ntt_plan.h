@@ -1,0 +1,36 @@
+// ntt_plan.h — pass planning shared by the launcher and the CPU replay harness.
+#pragma once
+#include "ntt_core.h"
+
+struct NttPassShape { int s_lo, mu, lambda, tau; };
+struct NttPlan { int npass; NttPassShape pass[2]; };
+
+// logn <= tau_max: one pass with the whole limb in LDS.  Otherwise two passes:
+// A = stages [0, floor(logn/2)) on strided columns, B = the remaining stages on contiguous chunks.
+inline NttPlan make_ntt_plan(int logn, int tau_max = 12) {
+    NttPlan p;
+    if (logn <= tau_max) {
+        p.npass = 1;
+        p.pass[0] = {0, logn, 0, logn};
+    } else {
+        int mu_a = logn / 2, mu_b = logn - mu_a;
+        p.npass = 2;
+        p.pass[0] = {0, mu_a, tau_max - mu_a, tau_max};
+        p.pass[1] = {mu_a, mu_b, 0, tau_max};
+    }
+    return p;
+}
+
+// fill the shape/direction fields of `a` for pass index `k` of a forward (inverse=0) or inverse transform;
+// passes of an inverse transform run in the order npass-1 .. 0.
+inline void ntt_fill_pass(NttPassArgs& a, const NttPlan& plan, int logn, int k, int inverse) {
+    const NttPassShape& s = plan.pass[k];
+    a.logn = logn;
+    a.s_lo = s.s_lo;
+    a.mu = s.mu;
+    a.lambda = s.lambda;
+    a.tau = s.tau;
+    a.inverse = inverse;
+    a.apply_scale = inverse && s.s_lo == 0;
+    a.final_reduce = inverse ? (k == 0) : (k == plan.npass - 1);
+}

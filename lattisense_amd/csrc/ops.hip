@@ -1,0 +1,377 @@
+// ops.hip — operator pipelines: the HEArithmeticOperator surface the reference's executors call
+// (mega_ag_runners/gpu/mega_ag_executors_gpu.cu:71-426), built from the kernels in kernels.hip.
+//
+// Algorithms follow the CPU path the results must agree with (Lattigo v4, restated in oracle/ls_oracle.c):
+//   key-switch  = per-digit exact ModUp (DecomposeSingleNTT) + gadget MAC + centred ModDown (ModDownQPtoQNTT)
+//   CKKS rescale = divide-and-round by the last prime (DivRoundByLastModulusNTT)
+//   rotate      = key-switch c1, add c0, then apply the automorphism (Evaluator.Automorphism)
+//   BFV mult    = centred extension Q->QMul, tensor in Q u QMul, round(./Q), centred return to Q, times t
+#include "lsa_internal.h"
+
+namespace lsa {
+
+static RowMap rm_seq(int count, int first = 0) {
+    RowMap r;
+    LSA_REQUIRE(count >= 1 && count <= LSA_MAX_PERIOD, "row map too long");
+    r.period = count;
+    for (int i = 0; i < count; i++) r.mod_of[i] = (unsigned char)(first + i);
+    return r;
+}
+
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------ key switch
+static size_t ks_ws_rows(const Context& c, int level) {
+    const int L = level + 1, T = L + c.np, beta = ceil_div(L, c.np);
+    return (size_t)L + (size_t)beta * T + 2 * (size_t)T + 2 * (size_t)L;
+}
+
+// p[h][i] = (h < base_polys ? base[h][i] : 0) + ModDown( sum_d ModUp_d(cx) * key_d[h] )[i]   (all NTT domain)
+static void key_switch(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
+                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s) {
+    LSA_REQUIRE(c.np >= 1, "key switching needs at least one special prime");
+    LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
+    const long long N = c.n;
+    const int L = level + 1, np = c.np, T = L + np, beta = ceil_div(L, np);
+    u64* cxi = ws;
+    u64* ext = cxi + (size_t)nb * L * N;
+    u64* acc = ext + (size_t)nb * beta * T * N;
+    u64* conv = acc + (size_t)nb * 2 * T * N;
+    const long long s_cxi = (long long)L * N, s_ext = (long long)beta * T * N, s_acc = 2LL * T * N, s_conv = 2LL * L * N;
+
+    // 1. cx out of the NTT domain
+    launch_ntt(c, cx, cxi, nb, scx, s_cxi, L, rm_seq(L), true, s);
+    // 2. per digit: exact conversion of the digit's limbs to every other limb of Q u P
+    auto tl_mod = [&](int tl) { return tl < L ? tl : c.p_mod(tl - L); };
+    for (int d = 0; d < beta; d++) {
+        const int d0 = d * np, d1 = std::min(d0 + np, L);
+        std::vector<int> src, dst;
+        BaseConvRows rows{};
+        for (int i = d0; i < d1; i++) {
+            rows.src_row[i - d0] = i;
+            src.push_back(i);
+        }
+        for (int tl = 0; tl < T; tl++) {
+            if (tl >= d0 && tl < d1) continue;
+            rows.dst_row[dst.size()] = d * T + tl;
+            dst.push_back(tl_mod(tl));
+        }
+        launch_baseconv(c, c.baseconv(src, dst, false), rows, cxi, ext, nb, s_cxi, s_ext, s);
+    }
+    // 3. extended limbs into the NTT domain (the digit's own limbs are taken from cx directly by the MAC)
+    if (beta * T <= LSA_MAX_PERIOD) {
+        RowMap rm;
+        rm.period = beta * T;
+        for (int d = 0; d < beta; d++)
+            for (int tl = 0; tl < T; tl++) {
+                const bool own = tl >= d * np && tl < std::min((d + 1) * np, L);
+                rm.mod_of[d * T + tl] = own ? LSA_ROW_SKIP : (unsigned char)tl_mod(tl);
+            }
+        launch_ntt(c, ext, ext, nb, s_ext, beta * T, rm, false, s);
+    } else {
+        for (int d = 0; d < beta; d++) {
+            RowMap rm;
+            rm.period = T;
+            for (int tl = 0; tl < T; tl++) {
+                const bool own = tl >= d * np && tl < std::min((d + 1) * np, L);
+                rm.mod_of[tl] = own ? LSA_ROW_SKIP : (unsigned char)tl_mod(tl);
+            }
+            launch_ntt(c, ext + (size_t)d * T * N, ext + (size_t)d * T * N, nb, s_ext, T, rm, false, s);
+        }
+    }
+    // 4. gadget inner product with the key (both halves)
+    launch_ks_mac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s);
+    // 5. ModDown: P-part out of NTT, centred exact conversion P -> Q, back to NTT, (accQ - conv) * P^-1 (+ base)
+    {
+        RowMap rm;
+        rm.period = 2 * T;
+        for (int h = 0; h < 2; h++)
+            for (int tl = 0; tl < T; tl++)
+                rm.mod_of[h * T + tl] = tl >= L ? (unsigned char)c.p_mod(tl - L) : LSA_ROW_SKIP;
+        launch_ntt(c, acc, acc, nb, s_acc, 2 * T, rm, true, s);
+    }
+    {
+        std::vector<int> src, dst;
+        BaseConvRows rows{};
+        for (int i = 0; i < np; i++) {
+            rows.src_row[i] = L + i;
+            src.push_back(c.p_mod(i));
+        }
+        for (int j = 0; j < L; j++) {
+            rows.dst_row[j] = j;
+            dst.push_back(j);
+        }
+        const BaseConvConsts* k = c.baseconv(src, dst, true);
+        for (int h = 0; h < 2; h++)
+            launch_baseconv(c, k, rows, acc + (size_t)h * T * N, conv + (size_t)h * L * N, nb, s_acc, s_conv, s);
+    }
+    launch_ntt(c, conv, conv, nb, s_conv, 2 * L, rm_seq(L), false, s);
+    launch_moddown_final(c, level, acc, s_acc, T, conv, s_conv, base, sbase, base_rpp, base_polys, p, sp, nb, s);
+}
+
+// ------------------------------------------------------------------------------------------------ rescale
+static size_t rescale_ws_rows(int level, int polys) { return (size_t)polys * (1 + level); }
+
+static void rescale(Context& c, int level, int polys, const u64* in, long long sin, u64* out, long long sout, int nb,
+                    bool ntt_domain, u64* ws, hipStream_t s) {
+    LSA_REQUIRE(level >= 1 && level < c.nq, "rescale needs level >= 1");
+    const long long N = c.n;
+    const int L = level + 1;
+    u64* last = ws;
+    u64* tmp = last + (size_t)nb * polys * N;
+    const long long s_last = (long long)polys * N, s_tmp = (long long)polys * level * N;
+    std::vector<int> rows(polys);
+    for (int p = 0; p < polys; p++) rows[p] = p * L + level;
+    launch_copy_rows(c, in, sin, last, s_last, polys, rows.data(), nb, s);
+    if (ntt_domain) {
+        RowMap rm;
+        rm.period = 1;
+        rm.mod_of[0] = (unsigned char)level;
+        launch_ntt(c, last, last, nb, s_last, polys, rm, true, s);
+    }
+    launch_rescale_prep(c, level, polys, last, s_last, tmp, s_tmp, nb, s);
+    if (ntt_domain) launch_ntt(c, tmp, tmp, nb, s_tmp, polys * level, rm_seq(level), false, s);
+    launch_rescale_final(c, level, polys, in, sin, tmp, s_tmp, out, sout, nb, s);
+}
+
+// ------------------------------------------------------------------------------------------------ tiling
+static int pick_tile(const Context& c, size_t rows_per_ct, int batch) {
+    if (c.tile_batch > 0) return std::min(c.tile_batch, batch);
+    // keep a tile's intermediates around the size of the 256 MiB Infinity Cache, but at least 1 ciphertext
+    const size_t bytes_per_ct = rows_per_ct * (size_t)c.n * sizeof(u64);
+    size_t tb = (192ull << 20) / std::max<size_t>(bytes_per_ct, 1);
+    if (tb < 1) tb = 1;
+    return (int)std::min<size_t>(tb, (size_t)batch);
+}
+
+// ================================================================================================ CKKS
+void ckks_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int batch, long long sa, long long sb,
+               long long sd, hipStream_t s) {
+    LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
+    launch_tensor(c, a, b, d3, batch, sa, sb, sd, level + 1, rm_seq(level + 1), s);
+}
+
+void ckks_relin(Context& c, int level, const u64* d3, const Key& rlk, u64* out, int batch, long long sd, long long so,
+                hipStream_t s) {
+    const long long N = c.n;
+    const int L = level + 1;
+    const size_t rows = ks_ws_rows(c, level);
+    const int tb = pick_tile(c, rows, batch);
+    u64* ws = c.workspace(rows * N * tb, s);
+    for (int b0 = 0; b0 < batch; b0 += tb) {
+        const int nb = std::min(tb, batch - b0);
+        const u64* d = d3 + (size_t)b0 * sd;
+        key_switch(c, level, d + 2LL * L * N, sd, rlk, out + (size_t)b0 * so, so, d, sd, L, 2, nb, ws, s);
+    }
+}
+
+void ckks_rescale(Context& c, int level, int polys, const u64* in, u64* out, int batch, long long sin, long long sout,
+                  hipStream_t s) {
+    const size_t rows = rescale_ws_rows(level, polys);
+    const int tb = pick_tile(c, rows, batch);
+    u64* ws = c.workspace(rows * c.n * tb, s);
+    for (int b0 = 0; b0 < batch; b0 += tb) {
+        const int nb = std::min(tb, batch - b0);
+        rescale(c, level, polys, in + (size_t)b0 * sin, sin, out + (size_t)b0 * sout, sout, nb, true, ws, s);
+    }
+}
+
+void ckks_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u64* out, int batch, long long sin,
+                 long long sout, hipStream_t s) {
+    const long long N = c.n;
+    const int L = level + 1;
+    const u32* perm = c.ntt_perm(g);
+    const size_t rows = ks_ws_rows(c, level) + 2 * (size_t)L;
+    const int tb = pick_tile(c, rows, batch);
+    u64* ws = c.workspace(rows * N * tb, s);
+    u64* p = ws + ks_ws_rows(c, level) * N * tb;
+    const long long sp = 2LL * L * N;
+    for (int b0 = 0; b0 < batch; b0 += tb) {
+        const int nb = std::min(tb, batch - b0);
+        const u64* ct = in + (size_t)b0 * sin;
+        key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, ct, sin, L, 1, nb, ws, s);
+        launch_permute_ntt(c, perm, p, sp, out + (size_t)b0 * sout, sout, 2 * L, nb, s);
+    }
+}
+
+void ckks_mult_relin_rescale(Context& c, int level, const u64* a, const u64* b, const Key& rlk, u64* out, int batch,
+                             long long sa, long long sb, long long so, hipStream_t s) {
+    LSA_REQUIRE(level >= 1, "mult+relin+rescale needs level >= 1");
+    const long long N = c.n;
+    const int L = level + 1;
+    const size_t r_d3 = 3 * (size_t)L, r_r2 = 2 * (size_t)L;
+    const size_t r_shared = std::max(ks_ws_rows(c, level), rescale_ws_rows(level, 2));
+    const size_t rows = r_d3 + r_r2 + r_shared;
+    const int tb = pick_tile(c, rows, batch);
+    u64* ws = c.workspace(rows * N * tb, s);
+    u64* d3 = ws;
+    u64* r2 = d3 + r_d3 * N * tb;
+    u64* sub = r2 + r_r2 * N * tb;
+    const long long sd = 3LL * L * N, sr = 2LL * L * N;
+    for (int b0 = 0; b0 < batch; b0 += tb) {
+        const int nb = std::min(tb, batch - b0);
+        launch_tensor(c, a + (size_t)b0 * sa, b + (size_t)b0 * sb, d3, nb, sa, sb, sd, L, rm_seq(L), s);
+        key_switch(c, level, d3 + 2LL * L * N, sd, rlk, r2, sr, d3, sd, L, 2, nb, sub, s);
+        rescale(c, level, 2, r2, sr, out + (size_t)b0 * so, so, nb, true, sub, s);
+    }
+}
+
+void drop_level(Context& c, int level, int polys, const u64* in, u64* out, int batch, long long sin, long long sout,
+                hipStream_t s) {
+    LSA_REQUIRE(level >= 1, "drop_level needs level >= 1");
+    std::vector<int> rows;
+    for (int p = 0; p < polys; p++)
+        for (int i = 0; i < level; i++) rows.push_back(p * (level + 1) + i);
+    launch_copy_rows(c, in, sin, out, sout, (int)rows.size(), rows.data(), batch, s);
+}
+
+void poly_addsub(Context& c, int op, int level, int polys, const u64* a, const u64* b, u64* out, int batch, long long sa,
+                 long long sb, long long so, hipStream_t s) {
+    LSA_REQUIRE(op >= 0 && op <= 2, "op must be 0 add, 1 sub, 2 neg");
+    LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
+    launch_elementwise(c, (EwOp)op, a, b, out, batch, sa, sb, so, polys * (level + 1), rm_seq(level + 1), s);
+}
+
+// ================================================================================================ BFV
+static int bfv_aux_limbs(const Context& c, int level) { return bfv_aux_count(c.T.mod.data(), level + 1, c.logn); }
+
+void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int batch, long long sa, long long sb,
+              long long sd, hipStream_t s) {
+    LSA_REQUIRE(c.algo == LSA_ALGO_BFV, "context is not BFV");
+    LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
+    const long long N = c.n;
+    const int L = level + 1, M = bfv_aux_limbs(c, level), T2 = L + M;
+    LSA_REQUIRE(M <= c.nmul, "auxiliary basis too small");
+    const size_t rows = 2 * 2 * (size_t)T2 + 3 * (size_t)T2 + 3 * (size_t)M;
+    const int tb = pick_tile(c, rows, batch);
+    u64* ws = c.workspace(rows * N * tb, s);
+    u64* ea = ws;
+    u64* eb = ea + (size_t)tb * 2 * T2 * N;
+    u64* d = eb + (size_t)tb * 2 * T2 * N;
+    u64* ext = d + (size_t)tb * 3 * T2 * N;
+    const long long s_e = 2LL * T2 * N, s_d = 3LL * T2 * N, s_x = 3LL * M * N;
+    std::vector<int> qmods, amods;
+    RowMap rmT;
+    rmT.period = T2;
+    for (int i = 0; i < L; i++) {
+        qmods.push_back(i);
+        rmT.mod_of[i] = (unsigned char)i;
+    }
+    for (int i = 0; i < M; i++) {
+        amods.push_back(c.aux_mod(i));
+        rmT.mod_of[L + i] = (unsigned char)c.aux_mod(i);
+    }
+    const BaseConvConsts* kQA = c.baseconv(qmods, amods, true);
+    const BaseConvConsts* kAQ = c.baseconv(amods, qmods, true);
+    BaseConvRows rQA{}, rAQ{};
+    for (int i = 0; i < L; i++) rQA.src_row[i] = i, rAQ.dst_row[i] = i;
+    for (int i = 0; i < M; i++) rQA.dst_row[i] = i, rAQ.src_row[i] = i;
+    std::vector<int> cp(2 * L);
+    // Q^-1 mod aux_i and t mod q_i
+    std::vector<u64> qinv(M), tq(L);
+    unsigned char lmA[LSA_MAX_PERIOD], lmQ[LSA_MAX_PERIOD];
+    for (int i = 0; i < M; i++) {
+        const u64 p = c.T.mod[c.aux_mod(i)];
+        u64 pr = 1;
+        for (int l = 0; l < L; l++) pr = mul_mod_host(pr, c.T.mod[l] % p, p);
+        qinv[i] = inv_mod(pr, p);
+        lmA[i] = (unsigned char)c.aux_mod(i);
+    }
+    for (int i = 0; i < L; i++) {
+        tq[i] = c.t % c.T.mod[i];
+        lmQ[i] = (unsigned char)i;
+    }
+    const u64* kQinv = c.const_vec("bfv_qinv" + std::to_string(L), amods, qinv);
+    const u64* kT = c.const_vec("bfv_t" + std::to_string(L), qmods, tq);
+
+    for (int b0 = 0; b0 < batch; b0 += tb) {
+        const int nb = std::min(tb, batch - b0);
+        const u64* srcs[2] = {a + (size_t)b0 * sa, b + (size_t)b0 * sb};
+        const long long ss[2] = {sa, sb};
+        u64* es[2] = {ea, eb};
+        const int nops = (a == b && sa == sb) ? 1 : 2;
+        for (int o = 0; o < nops; o++) {
+            for (int p = 0; p < 2; p++) {
+                // Q limbs copied, aux limbs by centred exact extension
+                std::vector<int> rr(L);
+                for (int i = 0; i < L; i++) rr[i] = p * L + i;
+                launch_copy_rows(c, srcs[o], ss[o], es[o] + (size_t)p * T2 * N, s_e, L, rr.data(), nb, s);
+                launch_baseconv(c, kQA, rQA, srcs[o] + (size_t)p * L * N, es[o] + ((size_t)p * T2 + L) * N, nb, ss[o],
+                                s_e, s);
+            }
+            launch_ntt(c, es[o], es[o], nb, s_e, 2 * T2, rmT, false, s);
+        }
+        launch_tensor(c, ea, nops == 1 ? ea : eb, d, nb, s_e, s_e, s_d, T2, rmT, s);
+        launch_ntt(c, d, d, nb, s_d, 3 * T2, rmT, true, s);
+        for (int k = 0; k < 3; k++)
+            launch_baseconv(c, kQA, rQA, d + (size_t)k * T2 * N, ext + (size_t)k * M * N, nb, s_d, s_x, s);
+        // aux part <- (aux - ext) * Q^-1     (= round(d/Q) in basis QMul)
+        launch_sub_mul_general(c, 3, M, lmA, kQinv, d + (size_t)L * N, s_d, T2, ext, s_x, M, nullptr, 0, 0, 0,
+                               d + (size_t)L * N, s_d, T2, nb, s);
+        u64* o3 = d3 + (size_t)b0 * sd;
+        for (int k = 0; k < 3; k++)
+            launch_baseconv(c, kAQ, rAQ, d + ((size_t)k * T2 + L) * N, o3 + (size_t)k * L * N, nb, s_d, sd, s);
+        launch_sub_mul_general(c, 3, L, lmQ, kT, o3, sd, L, nullptr, 0, 0, nullptr, 0, 0, 0, o3, sd, L, nb, s);
+    }
+}
+
+// key switch of a coefficient-domain polynomial: NTT in, INTT out
+static void bfv_key_switch(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
+                           int nb, u64* ws, hipStream_t s) {
+    const long long N = c.n;
+    const int L = level + 1;
+    u64* cxn = ws;
+    u64* sub = ws + (size_t)nb * L * N;
+    launch_ntt(c, cx, cxn, nb, scx, (long long)L * N, L, rm_seq(L), false, s);
+    key_switch(c, level, cxn, (long long)L * N, key, p, sp, nullptr, 0, 0, 0, nb, sub, s);
+    launch_ntt(c, p, p, nb, sp, 2 * L, rm_seq(L), true, s);
+}
+
+void bfv_relin(Context& c, int level, const u64* d3, const Key& rlk, u64* out, int batch, long long sd, long long so,
+               hipStream_t s) {
+    const long long N = c.n;
+    const int L = level + 1;
+    const size_t rows = ks_ws_rows(c, level) + L + 2 * (size_t)L;
+    const int tb = pick_tile(c, rows, batch);
+    u64* ws = c.workspace(rows * N * tb, s);
+    u64* p = ws + (ks_ws_rows(c, level) + L) * N * tb;
+    const long long sp = 2LL * L * N;
+    for (int b0 = 0; b0 < batch; b0 += tb) {
+        const int nb = std::min(tb, batch - b0);
+        const u64* d = d3 + (size_t)b0 * sd;
+        bfv_key_switch(c, level, d + 2LL * L * N, sd, rlk, p, sp, nb, ws, s);
+        launch_elementwise(c, EW_ADD, d, p, out + (size_t)b0 * so, nb, sd, sp, so, 2 * L, rm_seq(L), s);
+    }
+}
+
+void bfv_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u64* out, int batch, long long sin,
+                long long sout, hipStream_t s) {
+    const long long N = c.n;
+    const int L = level + 1;
+    const u32* perm = c.coeff_perm(g);
+    const size_t rows = ks_ws_rows(c, level) + L + 2 * (size_t)L;
+    const int tb = pick_tile(c, rows, batch);
+    u64* ws = c.workspace(rows * N * tb, s);
+    u64* p = ws + (ks_ws_rows(c, level) + L) * N * tb;
+    const long long sp = 2LL * L * N;
+    for (int b0 = 0; b0 < batch; b0 += tb) {
+        const int nb = std::min(tb, batch - b0);
+        const u64* ct = in + (size_t)b0 * sin;
+        bfv_key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, nb, ws, s);
+        launch_elementwise(c, EW_ADD, p, ct, p, nb, sp, sin, sp, L, rm_seq(L), s);  // p0 += c0
+        launch_permute_coeff(c, perm, p, sp, out + (size_t)b0 * sout, sout, 2 * L, rm_seq(L), nb, s);
+    }
+}
+
+void bfv_rescale(Context& c, int level, int polys, const u64* in, u64* out, int batch, long long sin, long long sout,
+                 hipStream_t s) {
+    const size_t rows = rescale_ws_rows(level, polys);
+    const int tb = pick_tile(c, rows, batch);
+    u64* ws = c.workspace(rows * c.n * tb, s);
+    for (int b0 = 0; b0 < batch; b0 += tb) {
+        const int nb = std::min(tb, batch - b0);
+        rescale(c, level, polys, in + (size_t)b0 * sin, sin, out + (size_t)b0 * sout, sout, nb, false, ws, s);
+    }
+}
+
+}  // namespace lsa

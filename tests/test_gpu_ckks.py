@@ -1,0 +1,129 @@
+"""GPU parity of the CKKS operators against the CPU oracle: bit-exact on identical inputs (real keys/ciphertexts from
+the test client), and the reference's own message-level assertion on the GPU output (mean precision >= 10 bits,
+unittests/test_gpu_ckks.cpp:37-43)."""
+import numpy as np
+import pytest
+
+from lattisense_amd import params
+from tests.gpu_util import need_gpu, rand_ct
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, nq, seed=3):
+    from lattisense_amd.device import DeviceContext, ALGO_CKKS
+    from oracle.client import Client
+    from oracle.pyoracle import Oracle
+    P = params.CKKS_DEFAULT[16384]
+    q, p = P["q"][:nq], P["p"]
+    return DeviceContext(ALGO_CKKS, n, q, p), Oracle(n, q, p, 0), q, p
+
+
+@pytest.mark.parametrize("n,lvl", [(1024, 4), (4096, 2), (8192, 5)])
+def test_mult_relin_rescale_bit_exact_and_decrypts(n, lvl):
+    need_gpu()
+    from oracle.client import Client, mean_precision_bits
+    ctx, o, q, p = _setup(n, 6)
+    c = Client(o, seed=n)
+    klvl = 5
+    rlk = c.gen_relin_key(klvl)
+    scale = float(2 ** 34)
+    rng = np.random.default_rng(1)
+    batch = 3
+    xs = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(batch)]
+    ys = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(batch)]
+    A = np.stack([c.ckks_encrypt(x, lvl, scale) for x in xs])
+    Bc = np.stack([c.ckks_encrypt(y, lvl, scale) for y in ys])
+    k = ctx.upload_key(rlk, klvl)
+    da, db = ctx.upload(A), ctx.upload(Bc)
+    # step by step
+    d3 = ctx.ckks_mult(lvl, da, db, batch)
+    want_d3 = np.stack([o.ckks_mult(lvl, A[i], Bc[i]) for i in range(batch)])
+    assert np.array_equal(ctx.download(d3, want_d3.shape), want_d3)
+    r2 = ctx.ckks_relin(lvl, d3, k, batch)
+    want_r2 = np.stack([o.ckks_relin(lvl, want_d3[i], rlk, klvl) for i in range(batch)])
+    assert np.array_equal(ctx.download(r2, want_r2.shape), want_r2)
+    rs = ctx.ckks_rescale(lvl, 2, r2, batch)
+    want_rs = np.stack([o.ckks_rescale(lvl, want_r2[i]) for i in range(batch)])
+    assert np.array_equal(ctx.download(rs, want_rs.shape), want_rs)
+    # fused entry point, with and without tiling
+    for tb in (0, 1, 2):
+        ctx.set_tile_batch(tb)
+        out = ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch)
+        got = ctx.download(out, want_rs.shape)
+        assert np.array_equal(got, want_rs)
+    for i in range(batch):
+        re, im = mean_precision_bits(xs[i] * ys[i], c.ckks_decrypt(got[i], scale * scale / q[lvl]))
+        assert re >= 10 and im >= 10
+    ctx.destroy_key(k)
+
+
+def test_rotate_conjugate_bit_exact_and_decrypts():
+    need_gpu()
+    from oracle.client import (Client, galois_element_for_col_rotation, galois_element_for_row_rotation,
+                               mean_precision_bits)
+    n, lvl, klvl = 2048, 3, 4
+    ctx, o, q, p = _setup(n, 5)
+    c = Client(o, seed=21)
+    scale = float(2 ** 34)
+    rng = np.random.default_rng(2)
+    batch = 2
+    xs = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(batch)]
+    A = np.stack([c.ckks_encrypt(x, lvl, scale) for x in xs])
+    da = ctx.upload(A)
+    for step, g in [(1, galois_element_for_col_rotation(1, n)), (-7, galois_element_for_col_rotation(-7, n)),
+                    (None, galois_element_for_row_rotation(n))]:
+        glk = c.gen_galois_key(g, klvl)
+        k = ctx.upload_key(glk, klvl)
+        out = ctx.ckks_rotate(lvl, da, g, k, batch)
+        want = np.stack([o.ckks_rotate(lvl, A[i], g, glk, klvl) for i in range(batch)])
+        got = ctx.download(out, want.shape)
+        assert np.array_equal(got, want)
+        for i in range(batch):
+            exp = np.conj(xs[i]) if step is None else np.roll(xs[i], -step)
+            re, im = mean_precision_bits(exp, c.ckks_decrypt(got[i], scale))
+            assert re >= 10 and im >= 10
+        ctx.destroy_key(k)
+
+
+def test_add_sub_neg_drop_level():
+    need_gpu()
+    n, lvl = 1024, 3
+    ctx, o, q, p = _setup(n, 4)
+    rng = np.random.default_rng(4)
+    batch = 2
+    A, Bc = rand_ct(rng, q, 2, n, batch), rand_ct(rng, q, 2, n, batch)
+    da, db = ctx.upload(A), ctx.upload(Bc)
+    for op, name in [(0, "add"), (1, "sub"), (2, "neg")]:
+        out = ctx.addsub(op, lvl, 2, da, db if op != 2 else None, batch)
+        got = ctx.download(out, A.shape)
+        for i in range(lvl + 1):
+            want = np.stack([[o.vec(name, i, A[b, pl, i], Bc[b, pl, i]) for pl in range(2)] for b in range(batch)])
+            assert np.array_equal(got[:, :, i], want)
+    out = ctx.drop_level(lvl, 2, da, batch)
+    assert np.array_equal(ctx.download(out, (batch, 2, lvl, n)), A[:, :, :lvl])
+
+
+def test_deep_chain_keyswitch_bootstrap_primes():
+    """digit width 5, 61-bit special primes, 60/40/39-bit chain (frontend/custom_task.py:387-420), L=12: beta=3 with a
+    short last digit; uniform-random 'key' and ciphertext (parity does not need a decryptable key)."""
+    need_gpu()
+    from lattisense_amd.device import DeviceContext, ALGO_CKKS
+    from oracle.pyoracle import Oracle
+    Bp = params.CKKS_BOOTSTRAP_65536
+    n, nq = 2048, 12
+    q, p = Bp["q"][:nq], Bp["p"]
+    lvl = klvl = nq - 1
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    o = Oracle(n, q, p, 0)
+    rng = np.random.default_rng(6)
+    batch = 2
+    A, Bc = rand_ct(rng, q, 2, n, batch), rand_ct(rng, q, 2, n, batch)
+    beta = (lvl + 1 + len(p) - 1) // len(p)
+    key = np.empty((beta, 2, lvl + 1 + len(p), n), dtype=np.uint64)
+    for j, m in enumerate(q + p):
+        key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+    k = ctx.upload_key(key, klvl)
+    out = ctx.ckks_mult_relin_rescale(lvl, ctx.upload(A), ctx.upload(Bc), k, batch)
+    want = np.stack([o.ckks_mult_relin_rescale(lvl, A[i], Bc[i], key, klvl) for i in range(batch)])
+    assert np.array_equal(ctx.download(out, want.shape), want)
