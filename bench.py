@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the RNS hot path on MI355X (BASELINE.json metric).
+
+Default workload (the configuration the metric is quoted on, BASELINE.json configs[2]):
+  CKKS N=2^16, level 12 (L=13 Q-limbs, k=4 special primes, beta=4 digits), HMult + relinearize + rescale,
+  batch 256 ciphertext pairs per GPU, inputs/keys resident in HBM, synthetic uniform residues.
+A "step" = one pass of the operator over the whole batch.  value = ciphertexts/s over all ranks.
+
+Other workloads (--workload): ntt (configs[1]: BFV N=2^14, 4 primes, batch 1024 cts fwd+inv NTT; value = GB/s),
+rotate (configs[3] shape per GPU), bfv_hmult (examples/benchmark_gpu shape), deep (configs[4] deep-chain key switch).
+
+Multi-GPU (torchrun, one rank per GPU): the ciphertext batch is sharded by index (weak scaling: `batch` per rank),
+no steady-state collective; rank 0 "ingests" the evaluation key and broadcasts it once over RCCL/xGMI.
+
+The JSON line also carries
+  roofline     — k_ntt_pass (dominant kernel): algorithmic bytes / HIP-event duration, sampled live in the timed region
+  cpu_baseline — the CPU oracle ("port") timed on rank 0's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep"])
+    ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU (0 = workload default)")
+    ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-stride", type=int, default=5)
+    return ap.parse_args()
+
+
+def workload_config(name):
+    from lattisense_amd import params
+    if name == "ckks_hmult":
+        P = params.CKKS_DEFAULT[65536]
+        return dict(algo=1, n=65536, q=P["q"][:13], p=P["p"], t=0, level=12, batch=256,
+                    label="CKKS N=2^16 L=13 k=4 HMult+relin+rescale", unit="ciphertexts/s",
+                    metric="ckks_hmult_relin_rescale_throughput")
+    if name == "rotate":
+        P = params.CKKS_DEFAULT[65536]
+        return dict(algo=1, n=65536, q=P["q"][:13], p=P["p"], t=0, level=12, batch=256,
+                    label="CKKS N=2^16 L=13 k=4 rotate (Galois key-switch)", unit="ciphertexts/s",
+                    metric="ckks_rotate_throughput")
+    if name == "bfv_hmult":
+        P = params.BFV_DEFAULT[16384]
+        return dict(algo=0, n=16384, q=P["q"], p=P["p"], t=P["t"], level=3, batch=1024,
+                    label="BFV N=2^14 level 3 mult+relin (examples/benchmark_gpu shape)", unit="ciphertexts/s",
+                    metric="bfv_hmult_relin_throughput")
+    if name == "deep":
+        P = params.CKKS_BOOTSTRAP_65536
+        return dict(algo=1, n=65536, q=P["q"], p=P["p"], t=0, level=24, batch=64,
+                    label="CKKS N=2^16 25Q+5P deep-chain HMult+relin+rescale", unit="ciphertexts/s",
+                    metric="ckks_deep_hmult_throughput")
+    P = params.BFV_DEFAULT[16384]
+    return dict(algo=0, n=16384, q=P["q"], p=P["p"], t=P["t"], level=3, batch=1024,
+                label="BFV N=2^14 4 primes batch 1024 ct NTT+INTT", unit="GB/s", metric="ntt_intt_algorithmic_bandwidth")
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from lattisense_amd._native import check, lib
+    from lattisense_amd.device import DeviceContext
+    L_ = lib()
+    cfg = workload_config(args.workload)
+    n, lvl = cfg["n"], cfg["level"]
+    L = lvl + 1
+    batch = args.batch or cfg["batch"]
+    ctx = DeviceContext(cfg["algo"], n, cfg["q"], cfg["p"], cfg["t"], device=local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.stream = ctypes.c_void_p(stream.cuda_stream)
+    if args.tile >= 0:
+        ctx.set_tile_batch(args.tile)
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+
+    def uniform(shape_prefix, mods):
+        """[..., len(mods), n] int64 tensor of uniform residues (synthetic data of the workload's shape)"""
+        out = torch.empty(*shape_prefix, len(mods), n, dtype=torch.int64, device=dev)
+        for i, m in enumerate(mods):
+            out[..., i, :] = torch.randint(0, m, (*shape_prefix, n), dtype=torch.int64, device=dev, generator=gen)
+        return out
+
+    class Buf:  # adapter: torch tensor -> object with .ptr for DeviceContext methods
+        def __init__(self, t):
+            self.t, self.ptr = t, t.data_ptr()
+
+    qs = cfg["q"][:L]
+    key = None
+    key_t = None
+    if args.workload != "ntt":
+        # evaluation key: rank 0 ingests, one-time broadcast to the other ranks over RCCL (xGMI), then read-only
+        np_ = len(cfg["p"])
+        beta = (L + np_ - 1) // np_
+        kmods = qs + cfg["p"]
+        if rank == 0:
+            key_t = uniform((beta, 2), kmods)
+        else:
+            key_t = torch.empty(beta, 2, len(kmods), n, dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.broadcast(key_t, src=0)
+        torch.cuda.synchronize()
+        assert key_t.numel() * 8 == ctx.key_bytes(lvl)
+        key = ctx.adopt_key(key_t.data_ptr(), lvl)
+
+    a = uniform((batch, 2), qs)
+    b = uniform((batch, 2), qs) if args.workload in ("ckks_hmult", "bfv_hmult", "deep") else None
+    if args.workload in ("ckks_hmult", "deep"):
+        out = torch.empty(batch, 2, lvl, n, dtype=torch.int64, device=dev)
+    else:
+        out = torch.empty(batch, 2, L, n, dtype=torch.int64, device=dev)
+    g_rot = pow(5, 1, 2 * n)
+
+    def step():
+        if args.workload in ("ckks_hmult", "deep"):
+            ctx.ckks_mult_relin_rescale(lvl, Buf(a), Buf(b), key, batch, out=Buf(out))
+        elif args.workload == "bfv_hmult":
+            ctx.bfv_mult_relin(lvl, Buf(a), Buf(b), key, batch, out=Buf(out))
+        elif args.workload == "rotate":
+            check(L_.lsa_ckks_rotate(ctx.h, lvl, a.data_ptr(), g_rot, key, out.data_ptr(), batch, 2 * L * n, 2 * L * n,
+                                     ctx.stream))
+        else:
+            mo = list(range(L))
+            ctx.ntt(Buf(a), batch, 2 * L, mo, inverse=False)
+            ctx.ntt(Buf(a), batch, 2 * L, mo, inverse=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    check(L_.lsa_profile_begin(ctx.h, args.prof_stride))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    check(L_.lsa_profile_end(ctx.h))
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    if args.workload == "ntt":
+        # 2 transforms (fwd+inv) x batch*2*L limbs x 16N algorithmic bytes
+        value = world * 2 * batch * 2 * L * 16.0 * n / (dt / args.steps) / 1e9
+    else:
+        value = world * batch * args.steps / dt
+
+    # ---- roofline of the dominant kernel (k_ntt_pass), from the sampled HIP events of the timed region
+    def prof(kind):
+        ms, by = ctypes.c_double(), ctypes.c_double()
+        ns, nl = ctypes.c_longlong(), ctypes.c_longlong()
+        check(L_.lsa_profile_read(ctx.h, kind, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(ns), ctypes.byref(nl)))
+        return ms.value, by.value, ns.value, nl.value
+
+    kinds = {0: "k_ntt_pass", 1: "k_baseconv", 2: "k_ks_mac", 3: "k_tensor", 4: "elementwise"}
+    breakdown = {}
+    for kid, name in kinds.items():
+        ms, by, ns, nl = prof(kid)
+        if ns:
+            breakdown[name] = {"est_ms_per_step": ms / ns * nl / args.steps, "avg_launch_us": ms / ns * 1e3,
+                               "achieved_GBps": by / ms / 1e6, "launches_per_step": nl / args.steps}
+    ntt = breakdown.get("k_ntt_pass", None)
+    roofline = None
+    if ntt:
+        roofline = {"kernel": "k_ntt_pass", "bound": "hbm", "achieved": ntt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": ntt["achieved_GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                    "avg_launch_us": ntt["avg_launch_us"], "launches_per_step": ntt["launches_per_step"],
+                    "sampling": "HIP event pair around every %d-th launch, on the launch stream" % args.prof_stride}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, cfg)
+
+    if rank == 0:
+        line = {
+            "metric": cfg["metric"], "value": value, "unit": cfg["unit"], "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": cfg["label"], "batch_per_gpu": batch, "ring_degree": n, "q_limbs": L,
+                       "special_primes": len(cfg["p"]), "sharding": "ciphertext batch by rank; key broadcast once"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(workload, cfg):
+    """Times the CPU oracle (a plain-C restatement, `kind: port`) on a bounded sample of the same workload,
+    one ciphertext per thread over the host cores available to this process."""
+    import numpy as np
+    from oracle.pyoracle import Oracle
+    n, lvl = cfg["n"], cfg["level"]
+    L = lvl + 1
+    cores = max(1, min(len(os.sched_getaffinity(0)), 32))
+    o = Oracle(n, cfg["q"], cfg["p"], cfg["t"])
+    rng = np.random.default_rng(0)
+    qs = cfg["q"][:L]
+
+    def rand_ct():
+        ct = np.empty((2, L, n), dtype=np.uint64)
+        for i, m in enumerate(qs):
+            ct[:, i, :] = rng.integers(0, m, size=(2, n), dtype=np.uint64)
+        return ct
+
+    key = None
+    if workload != "ntt":
+        np_ = len(cfg["p"])
+        beta = (L + np_ - 1) // np_
+        key = np.empty((beta, 2, L + np_, n), dtype=np.uint64)
+        for j, m in enumerate(qs + cfg["p"]):
+            key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+    a, b = rand_ct(), rand_ct()
+    per_thread = 1
+    done = []
+
+    def work():
+        for _ in range(per_thread):
+            if workload in ("ckks_hmult", "deep"):
+                o.ckks_mult_relin_rescale(lvl, a, b, key, lvl)
+            elif workload == "bfv_hmult":
+                o.bfv_mult_relin(lvl, a, b, key, lvl)
+            elif workload == "rotate":
+                o.ckks_rotate(lvl, a, 5, key, lvl)
+            else:
+                for p in range(2):
+                    for i in range(L):
+                        o.intt(i, o.ntt(i, a[p, i]))
+            done.append(1)
+
+    th = [threading.Thread(target=work) for _ in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    units = len(done)
+    if workload == "ntt":
+        val, unit = units * 2 * 2 * L * 16.0 * n / dt / 1e9, "GB/s"
+    else:
+        val, unit = units / dt, "ciphertexts/s"
+    return {"value": val, "unit": unit, "cores": cores, "kind": "port",
+            "sample": "%d ciphertext op(s) of the same shape, one per thread, oracle/ls_oracle.c (gcc -O2), %.1f s wall"
+                      % (units, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,13 @@ int lsa_bfv_mult_relin(lsa_context ctx, int level, const uint64_t* a, const uint
 /* ---- tuning / introspection */
 /* ciphertexts processed per kernel wave inside the fused operators (0 = automatic) */
 int lsa_set_tile_batch(lsa_context ctx, int tile_batch);
+/* Sampled HIP-event timing of the library's own kernel launches, recorded on the stream they are launched on (every
+ * `stride`-th launch of each kind gets an event pair).  kind: 0 NTT pass, 1 base conversion, 2 key-switch MAC,
+ * 3 tensor, 4 other element-wise.  total_bytes = ALGORITHMIC bytes of the sampled launches. */
+int lsa_profile_begin(lsa_context ctx, int stride);
+int lsa_profile_end(lsa_context ctx);
+int lsa_profile_read(lsa_context ctx, int kind, double* total_ms, double* total_bytes, long long* sampled,
+                     long long* launched);
 /* micro-benchmark kernels used by bench.py / DESIGN.md to report the integer-multiply and copy ceilings */
 int lsa_probe_copy(lsa_context ctx, uint64_t* dst, const uint64_t* src, size_t n_u64, void* stream);
 int lsa_probe_mulhi(lsa_context ctx, uint64_t* buf, size_t n_u64, int iters, void* stream);

@@ -292,6 +292,46 @@ int lsa_bfv_mult_relin(lsa_context ctx, int level, const uint64_t* a, const uint
     });
 }
 
+int lsa_profile_begin(lsa_context ctx, int stride) {
+    return guard([&] {
+        Context& c = C(ctx);
+        LSA_REQUIRE(stride >= 1, "stride must be >= 1");
+        for (auto& sm : c.prof_samples) {
+            c.prof_pool.push_back(sm.e0);
+            c.prof_pool.push_back(sm.e1);
+        }
+        c.prof_samples.clear();
+        for (auto& n : c.prof_launched) n = 0;
+        c.prof_stride = stride;
+        c.prof_on = true;
+    });
+}
+int lsa_profile_end(lsa_context ctx) {
+    return guard([&] { C(ctx).prof_on = false; });
+}
+int lsa_profile_read(lsa_context ctx, int kind, double* total_ms, double* total_bytes, long long* sampled,
+                     long long* launched) {
+    return guard([&] {
+        Context& c = C(ctx);
+        LSA_REQUIRE(kind >= 0 && kind < LSA_PROF_KINDS, "unknown kernel kind");
+        double ms = 0, by = 0;
+        long long n = 0;
+        for (auto& sm : c.prof_samples) {
+            if (sm.kid != kind) continue;
+            LSA_HIP(hipEventSynchronize(sm.e1));
+            float t = 0;
+            LSA_HIP(hipEventElapsedTime(&t, sm.e0, sm.e1));
+            ms += t;
+            by += sm.bytes;
+            n++;
+        }
+        if (total_ms) *total_ms = ms;
+        if (total_bytes) *total_bytes = by;
+        if (sampled) *sampled = n;
+        if (launched) *launched = c.prof_launched[kind];
+    });
+}
+
 int lsa_set_tile_batch(lsa_context ctx, int tile_batch) {
     return guard([&] {
         LSA_REQUIRE(tile_batch >= 0, "tile_batch must be >= 0");

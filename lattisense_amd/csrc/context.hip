@@ -55,7 +55,12 @@ Context::~Context() {
     (void)hipFree(d_scale);
     (void)hipFree(ws);
     (void)hipFree(ws2);
-    for (auto& kv : bconv) (void)hipFree(kv.second);
+    for (auto& sm : prof_samples) {
+        (void)hipEventDestroy(sm.e0);
+        (void)hipEventDestroy(sm.e1);
+    }
+    for (auto& e : prof_pool) (void)hipEventDestroy(e);
+    for (auto& kv : bconv) (void)hipFree(kv.second.dev);
     for (auto& kv : perm_ntt) (void)hipFree(kv.second);
     for (auto& kv : perm_coeff) (void)hipFree(kv.second);
     for (auto& kv : consts) (void)hipFree(kv.second);
@@ -86,14 +91,14 @@ u64* Context::workspace2(size_t words, hipStream_t s) {
     return ws2;
 }
 
-const BaseConvConsts* Context::baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered) {
+const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered) {
     std::string key = centered ? "c" : "u";
     for (int x : src) key += "|" + std::to_string(x);
     key += "->";
     for (int x : dst) key += "|" + std::to_string(x);
     std::lock_guard<std::mutex> lk(mu);
     auto it = bconv.find(key);
-    if (it != bconv.end()) return it->second;
+    if (it != bconv.end()) return &it->second;
     const int ns = (int)src.size(), nd = (int)dst.size();
     LSA_REQUIRE(ns >= 1 && ns <= LSA_BC_MAX_SRC && nd >= 1 && nd <= LSA_BC_MAX_DST, "base conversion too wide");
     auto K = std::make_unique<BaseConvConsts>();
@@ -128,8 +133,12 @@ const BaseConvConsts* Context::baseconv(const std::vector<int>& src, const std::
     BaseConvConsts* d = nullptr;
     LSA_HIP(hipMalloc((void**)&d, sizeof(BaseConvConsts)));
     LSA_HIP(hipMemcpy(d, K.get(), sizeof(BaseConvConsts), hipMemcpyHostToDevice));
-    bconv[key] = d;
-    return d;
+    BaseConvPlan pl;
+    pl.dev = d;
+    pl.ns = ns;
+    pl.nd = nd;
+    bconv[key] = pl;
+    return &bconv[key];
 }
 
 static unsigned brv_bits(unsigned x, int bits) {

@@ -65,6 +65,10 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         const long long nblocks = (long long)batch * rows * (1 << (a.logn - a.tau));
         LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
         const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
+        int active_rows = 0;
+        for (int r = 0; r < rows; r++) active_rows += rm.mod_of[r % rm.period] != LSA_ROW_SKIP;
+        // one launch = one pass = 1/npass of the limb transforms it touches (algorithmic 16*N bytes per transform)
+        ProfScope ps(c, PROF_NTT, 16.0 * c.n * active_rows * batch / c.plan.npass, s);
         hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
         LSA_HIP(hipGetLastError());
     }
@@ -149,6 +153,7 @@ void launch_elementwise(Context& c, EwOp op, const u64* a, const u64* b, u64* ou
     g.logn = c.logn;
     g.op = op;
     fill_rowmap(g.mod_of, g.period, rm, c.nmod);
+    ProfScope ps(c, PROF_ELEMWISE, 24.0 * c.n * rows * batch, s);
     hipLaunchKernelGGL(k_elementwise, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
@@ -207,6 +212,7 @@ void launch_tensor(Context& c, const u64* a, const u64* b, u64* d, int batch, lo
     LSA_REQUIRE(rm.period == limbs && limbs <= LSA_MAX_PERIOD, "tensor: row map must cover the limbs");
     int period;
     fill_rowmap(g.mod_of, period, rm, c.nmod);
+    ProfScope ps(c, PROF_TENSOR, 7.0 * 8 * c.n * limbs * batch, s);
     hipLaunchKernelGGL(k_tensor, ew_grid(c, limbs, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
@@ -278,11 +284,11 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
     }
 }
 
-void launch_baseconv(Context& c, const BaseConvConsts* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
+void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
                      long long ssrc, long long sdst, hipStream_t s) {
     if (batch <= 0) return;
     BaseConvArgs g{};
-    g.k = k;
+    g.k = k->dev;
     g.mods = c.d_mods;
     g.src = src;
     g.dst = dst;
@@ -290,6 +296,7 @@ void launch_baseconv(Context& c, const BaseConvConsts* k, const BaseConvRows& ro
     g.sdst = sdst;
     g.logn = c.logn;
     g.rows = rows;
+    ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns + k->nd), s);
     hipLaunchKernelGGL(k_baseconv, dim3((unsigned)(c.n / (2 * TPB)), (unsigned)batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
@@ -365,6 +372,8 @@ void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u6
     g.klvl = key.level;
     g.kcomp = key.level + 1 + c.np;
     LSA_REQUIRE(key.level >= level, "key-switch key exported at a lower level than the ciphertext");
+    const double T = g.L + c.np;
+    ProfScope ps(c, PROF_KSMAC, 8.0 * c.n * (batch * (g.beta * T + 2 * T) + 2.0 * g.beta * T), s);
     hipLaunchKernelGGL(k_ks_mac, ew_grid(c, g.L + c.np, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
@@ -433,6 +442,7 @@ void launch_sub_mul_general(Context& c, int polys, int limbs, const unsigned cha
     g.mods = c.d_mods;
     LSA_REQUIRE(limbs <= LSA_MAX_PERIOD, "too many limbs");
     for (int i = 0; i < limbs; i++) g.mod_of[i] = limb_mod[i];
+    ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * polys * limbs * batch * (2 + (b != nullptr) + (base != nullptr)), s);
     hipLaunchKernelGGL(k_sub_mul, ew_grid(c, polys * limbs, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
@@ -505,6 +515,7 @@ void launch_rescale_prep(Context& c, int level, int polys, const u64* last, long
     g.level = level;
     g.polys = polys;
     g.logn = c.logn;
+    ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * polys * (level + 1) * batch, s);
     hipLaunchKernelGGL(k_rescale_prep, ew_grid(c, polys * level, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
@@ -567,6 +578,7 @@ void launch_permute_ntt(Context& c, const u32* perm, const u64* in, long long si
     g.logn = c.logn;
     g.with_sign = 0;
     g.period = 1;
+    ProfScope ps(c, PROF_ELEMWISE, 16.0 * c.n * rows * batch, s);
     hipLaunchKernelGGL(k_permute, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
@@ -585,6 +597,7 @@ void launch_permute_coeff(Context& c, const u32* perm, const u64* in, long long 
     g.logn = c.logn;
     g.with_sign = 1;
     fill_rowmap(g.mod_of, g.period, rm, c.nmod);
+    ProfScope ps(c, PROF_ELEMWISE, 16.0 * c.n * rows * batch, s);
     hipLaunchKernelGGL(k_permute, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
@@ -619,6 +632,7 @@ void launch_copy_rows(Context& c, const u64* in, long long sin, u64* out, long l
     g.rows = rows;
     g.logn = c.logn;
     for (int i = 0; i < rows; i++) g.src_row[i] = (short)src_row[i];
+    ProfScope ps(c, PROF_ELEMWISE, 16.0 * c.n * rows * batch, s);
     hipLaunchKernelGGL(k_copy_rows, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }

@@ -52,6 +52,13 @@ struct BaseConvConsts {
     u64 half_dst[LSA_BC_MAX_DST];                   // floor(S/2) mod p_j
 };
 
+struct BaseConvPlan {
+    BaseConvConsts* dev = nullptr;
+    int ns = 0, nd = 0;
+};
+
+enum ProfKind { PROF_NTT = 0, PROF_BASECONV = 1, PROF_KSMAC = 2, PROF_TENSOR = 3, PROF_ELEMWISE = 4, LSA_PROF_KINDS = 5 };
+
 struct Key {
     u64* data = nullptr;   // device, compact order [beta][2][klvl+1+np][N], NTT domain, MONTGOMERY form
     int level = 0;
@@ -69,8 +76,20 @@ struct Context {
     u64* d_scale = nullptr;
     int tile_batch = 0;
 
+    // sampled HIP-event timing of kernel launches (bench.py roofline leg); off unless lsa_profile_begin was called
+    struct ProfSample {
+        hipEvent_t e0, e1;
+        int kid;
+        double bytes;
+    };
+    bool prof_on = false;
+    int prof_stride = 1;
+    long long prof_launched[LSA_PROF_KINDS] = {0};
+    std::vector<ProfSample> prof_samples;
+    std::vector<hipEvent_t> prof_pool;
+
     std::mutex mu;
-    std::map<std::string, BaseConvConsts*> bconv;   // device copies, keyed by "c|src..|dst.."
+    std::map<std::string, BaseConvPlan> bconv;       // device copies, keyed by "c|src..|dst.."
     std::map<u64, u32*> perm_ntt;                   // galois element -> device gather table (NTT domain)
     std::map<u64, u32*> perm_coeff;                 // galois element -> device scatter table with sign bit
     std::map<std::string, u64*> consts;             // misc per-level device constant vectors
@@ -88,11 +107,45 @@ struct Context {
     u64* workspace2(size_t words, hipStream_t s);
     int p_mod(int i) const { return nq + i; }
     int aux_mod(int i) const { return nq + np + i; }
-    const BaseConvConsts* baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered);
+    const BaseConvPlan* baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered);
     const u32* ntt_perm(u64 g);
     const u32* coeff_perm(u64 g);
     // per-modulus constant vector on device, Montgomery form, built by `gen(mod_index)`
     const u64* const_vec(const std::string& name, const std::vector<int>& mods, const std::vector<u64>& plain_vals);
+};
+
+// RAII sample of one kernel launch: records an event pair around every prof_stride-th launch of a kind
+struct ProfScope {
+    Context& c;
+    hipStream_t s;
+    bool active = false;
+    Context::ProfSample smp{};
+    ProfScope(Context& c_, int kid, double bytes, hipStream_t s_) : c(c_), s(s_) {
+        if (!c.prof_on) return;
+        const long long idx = c.prof_launched[kid]++;
+        if (idx % c.prof_stride != 0) return;
+        auto take = [&]() {
+            hipEvent_t e;
+            if (!c.prof_pool.empty()) {
+                e = c.prof_pool.back();
+                c.prof_pool.pop_back();
+            } else {
+                LSA_HIP(hipEventCreate(&e));
+            }
+            return e;
+        };
+        smp.e0 = take();
+        smp.e1 = take();
+        smp.kid = kid;
+        smp.bytes = bytes;
+        LSA_HIP(hipEventRecord(smp.e0, s));
+        active = true;
+    }
+    ~ProfScope() {
+        if (!active) return;
+        (void)hipEventRecord(smp.e1, s);
+        c.prof_samples.push_back(smp);
+    }
 };
 
 // ---------------------------------------------------------------- launchers (kernels.hip)
@@ -118,7 +171,7 @@ struct BaseConvRows {
     int src_row[LSA_BC_MAX_SRC];
     int dst_row[LSA_BC_MAX_DST];
 };
-void launch_baseconv(Context& c, const BaseConvConsts* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
+void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
                      long long ssrc, long long sdst, hipStream_t s);
 // key-switch inner product: acc[h][tl] = sum_d ext(d,tl) * key[d][h][tl];  ext(d,tl) = cx[tl] when tl is in digit d
 void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext,

@@ -101,7 +101,7 @@ static void key_switch(Context& c, int level, const u64* cx, long long scx, cons
             rows.dst_row[j] = j;
             dst.push_back(j);
         }
-        const BaseConvConsts* k = c.baseconv(src, dst, true);
+        const BaseConvPlan* k = c.baseconv(src, dst, true);
         for (int h = 0; h < 2; h++)
             launch_baseconv(c, k, rows, acc + (size_t)h * T * N, conv + (size_t)h * L * N, nb, s_acc, s_conv, s);
     }
@@ -261,8 +261,8 @@ void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int ba
         amods.push_back(c.aux_mod(i));
         rmT.mod_of[L + i] = (unsigned char)c.aux_mod(i);
     }
-    const BaseConvConsts* kQA = c.baseconv(qmods, amods, true);
-    const BaseConvConsts* kAQ = c.baseconv(amods, qmods, true);
+    const BaseConvPlan* kQA = c.baseconv(qmods, amods, true);
+    const BaseConvPlan* kAQ = c.baseconv(amods, qmods, true);
     BaseConvRows rQA{}, rAQ{};
     for (int i = 0; i < L; i++) rQA.src_row[i] = i, rAQ.dst_row[i] = i;
     for (int i = 0; i < M; i++) rQA.dst_row[i] = i, rAQ.src_row[i] = i;
