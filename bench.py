@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep"])
     ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU (0 = workload default)")
     ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
+    ap.add_argument("--ntt-chunk-mib", type=int, default=-1, help="Infinity-Cache chunk of two-pass NTTs (-1 = default)")
+    ap.add_argument("--int-ntt", action="store_true", help="force the integer butterfly engine (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=5)
     return ap.parse_args()
@@ -98,6 +100,10 @@ def main():
     ctx.stream = ctypes.c_void_p(stream.cuda_stream)
     if args.tile >= 0:
         ctx.set_tile_batch(args.tile)
+    if args.ntt_chunk_mib >= 0:
+        check(L_.lsa_set_ntt_chunk_mib(ctx.h, args.ntt_chunk_mib))
+    if args.int_ntt:
+        ctx.set_fp64_ntt(False)
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)

@@ -116,6 +116,12 @@ int lsa_bfv_mult_relin(lsa_context ctx, int level, const uint64_t* a, const uint
 /* ---- tuning / introspection */
 /* ciphertexts processed per kernel wave inside the fused operators (0 = automatic) */
 int lsa_set_tile_batch(lsa_context ctx, int tile_batch);
+/* NTT butterfly engine for limbs with q < 2^47: 1 (default) = exact FP64-FMA butterflies, 0 = integer Montgomery for
+ * every limb.  Both produce identical residues; the switch exists for A/B measurement and parity tests. */
+int lsa_set_fp64_ntt(lsa_context ctx, int enable);
+/* Two-pass NTTs (N > 2^12) run both passes over a chunk of at most `mib` MiB of limbs before moving on, so that the
+ * second pass is served by the 256 MiB Infinity Cache (0 = one launch per pass over the whole batch). */
+int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib);
 /* Sampled HIP-event timing of the library's own kernel launches, recorded on the stream they are launched on (every
  * `stride`-th launch of each kind gets an event pair).  kind: 0 NTT pass, 1 base conversion, 2 key-switch MAC,
  * 3 tensor, 4 other element-wise.  total_bytes = ALGORITHMIC bytes of the sampled launches. */

@@ -43,7 +43,8 @@ def build_native(force=False, verbose=False):
         if force or _stale(obj, [sp] + hdrs):
             if src.endswith(".hip"):
                 cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                       "-fno-fast-math", "-Wall", "-Wno-unused-result", "-c", sp, "-o", obj]
+                       "-fno-fast-math", "-Wall", "-Wno-unused-result"] + os.environ.get("LSA_EXTRA_FLAGS", "").split() + \
+                      ["-c", sp, "-o", obj]
             else:
                 cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-I/opt/rocm/include",
                        "-D__HIP_PLATFORM_AMD__", "-c", sp, "-o", obj]

@@ -332,6 +332,15 @@ int lsa_profile_read(lsa_context ctx, int kind, double* total_ms, double* total_
     });
 }
 
+int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib) {
+    return guard([&] {
+        LSA_REQUIRE(mib >= 0, "chunk size must be >= 0");
+        C(ctx).ntt_chunk_mib = mib;
+    });
+}
+int lsa_set_fp64_ntt(lsa_context ctx, int enable) {
+    return guard([&] { C(ctx).fp64_ntt = enable ? 1 : 0; });
+}
 int lsa_set_tile_batch(lsa_context ctx, int tile_batch) {
     return guard([&] {
         LSA_REQUIRE(tile_batch >= 0, "tile_batch must be >= 0");

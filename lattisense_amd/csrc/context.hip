@@ -44,6 +44,12 @@ Context::Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_
     LSA_HIP(hipMemcpy(d_psi, T.psi.data(), tw_bytes, hipMemcpyHostToDevice));
     LSA_HIP(hipMemcpy(d_psiinv, T.psiinv.data(), tw_bytes, hipMemcpyHostToDevice));
     LSA_HIP(hipMemcpy(d_scale, T.scale.data(), (size_t)nmod * 2 * sizeof(u64), hipMemcpyHostToDevice));
+    LSA_HIP(hipMalloc((void**)&d_psi_d, tw_bytes));
+    LSA_HIP(hipMalloc((void**)&d_psiinv_d, tw_bytes));
+    LSA_HIP(hipMalloc((void**)&d_scale_d, (size_t)nmod * 2 * sizeof(double)));
+    LSA_HIP(hipMemcpy(d_psi_d, T.psi_d.data(), tw_bytes, hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_psiinv_d, T.psiinv_d.data(), tw_bytes, hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_scale_d, T.scale_d.data(), (size_t)nmod * 2 * sizeof(double), hipMemcpyHostToDevice));
 }
 
 Context::~Context() {
@@ -53,6 +59,9 @@ Context::~Context() {
     (void)hipFree(d_psi);
     (void)hipFree(d_psiinv);
     (void)hipFree(d_scale);
+    (void)hipFree(d_psi_d);
+    (void)hipFree(d_psiinv_d);
+    (void)hipFree(d_scale_d);
     (void)hipFree(ws);
     (void)hipFree(ws2);
     for (auto& sm : prof_samples) {

@@ -6,7 +6,7 @@
 #include "tables.h"
 
 extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int batch, long long batch_stride, int rows,
-                           const unsigned char* mod_of, int period, int inverse, int tau_max) {
+                           const unsigned char* mod_of, int period, int inverse, int tau_max, int allow_fp64) {
     lsa::HostTables T;
     T.build(n, std::vector<u64>(moduli, moduli + nmod));
     NttPlan plan = make_ntt_plan(T.logn, tau_max);
@@ -20,6 +20,9 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
     a.mods = T.mods.data();
     a.tw = inverse ? T.psiinv.data() : T.psi.data();
     a.scale = T.scale.data();
+    a.twd = inverse ? T.psiinv_d.data() : T.psi_d.data();
+    a.scaled = T.scale_d.data();
+    a.allow_fp64 = allow_fp64;
     a.period = period;
     for (int i = 0; i < period; i++) a.mod_of[i] = mod_of[i];
     for (int step = 0; step < plan.npass; step++) {
@@ -31,7 +34,7 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
             NttBlockCtx bc = ntt_decode_block(a, bid);
             if (bc.mod == LSA_ROW_SKIP) continue;
             for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_load(a, bc, t, lds.data());
-            int np = (a.mu + 3) / 4, base = a.mu / np, extra = a.mu % np;
+            int np = (a.mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO, base = a.mu / np, extra = a.mu % np;
             if (!inverse) {
                 int sig = 0;
                 for (int i = 0; i < np; i++) {

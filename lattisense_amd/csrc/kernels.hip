@@ -7,14 +7,17 @@ namespace lsa {
 static constexpr int TPB = 256;
 
 // ------------------------------------------------------------------------------------------------ K1/K2 NTT pass
-__global__ __launch_bounds__(LSA_NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
+#ifndef LSA_NTT_WAVES
+#define LSA_NTT_WAVES 3   // min waves/SIMD the register allocator must allow (= co-resident 256-thread workgroups per CU)
+#endif
+__global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
     if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
     const int tid = threadIdx.x;
     ntt_phase_load(a, bc, tid, lds);
     __syncthreads();
-    const int np = (a.mu + 3) / 4, base = a.mu / np, extra = a.mu % np;
+    const int np = (a.mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO, base = a.mu / np, extra = a.mu % np;
     if (!a.inverse) {
         int sig = 0;
         for (int i = 0; i < np; i++) {
@@ -50,27 +53,41 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
     a.mods = c.d_mods;
     a.tw = inverse ? c.d_psiinv : c.d_psi;
     a.scale = c.d_scale;
+    a.twd = inverse ? c.d_psiinv_d : c.d_psi_d;
+    a.scaled = c.d_scale_d;
+    a.allow_fp64 = c.fp64_ntt;
     a.period = rm.period;
     for (int i = 0; i < rm.period; i++) {
         LSA_REQUIRE(rm.mod_of[i] == LSA_ROW_SKIP || rm.mod_of[i] < c.nmod, "ntt: modulus index out of range");
         a.mod_of[i] = rm.mod_of[i];
     }
-    for (int step = 0; step < c.plan.npass; step++) {
-        const int k = inverse ? c.plan.npass - 1 - step : step;
-        ntt_fill_pass(a, c.plan, c.logn, k, inverse ? 1 : 0);
-        a.src = step == 0 ? src : dst;
-        a.src_stride = step == 0 ? src_stride : dst_stride;
-        a.dst = dst;
-        a.dst_stride = dst_stride;
-        const long long nblocks = (long long)batch * rows * (1 << (a.logn - a.tau));
-        LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
-        const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
-        int active_rows = 0;
-        for (int r = 0; r < rows; r++) active_rows += rm.mod_of[r % rm.period] != LSA_ROW_SKIP;
-        // one launch = one pass = 1/npass of the limb transforms it touches (algorithmic 16*N bytes per transform)
-        ProfScope ps(c, PROF_NTT, 16.0 * c.n * active_rows * batch / c.plan.npass, s);
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
-        LSA_HIP(hipGetLastError());
+    int active_rows = 0;
+    for (int r = 0; r < rows; r++) active_rows += rm.mod_of[r % rm.period] != LSA_ROW_SKIP;
+    // Two-pass transforms: run both passes on a chunk of the batch that fits the 256 MiB Infinity Cache before moving
+    // on, so the second pass reads what the first just wrote from the memory-side cache instead of HBM.
+    int chunk = batch;
+    if (c.plan.npass > 1 && c.ntt_chunk_mib > 0) {
+        const double per_item = 8.0 * c.n * std::max(active_rows, 1);
+        chunk = (int)std::max(1.0, std::min((double)batch, c.ntt_chunk_mib * 1048576.0 / per_item));
+    }
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = std::min(chunk, batch - b0);
+        a.batch = nb;
+        for (int step = 0; step < c.plan.npass; step++) {
+            const int k = inverse ? c.plan.npass - 1 - step : step;
+            ntt_fill_pass(a, c.plan, c.logn, k, inverse ? 1 : 0);
+            a.src = (step == 0 ? src + (long long)b0 * src_stride : dst + (long long)b0 * dst_stride);
+            a.src_stride = step == 0 ? src_stride : dst_stride;
+            a.dst = dst + (long long)b0 * dst_stride;
+            a.dst_stride = dst_stride;
+            const long long nblocks = (long long)nb * rows * (1 << (a.logn - a.tau));
+            LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
+            const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
+            // one launch = one pass = 1/npass of the limb transforms it touches (algorithmic 16*N bytes per transform)
+            ProfScope ps(c, PROF_NTT, 16.0 * c.n * active_rows * nb / c.plan.npass, s);
+            hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
+            LSA_HIP(hipGetLastError());
+        }
     }
 }
 
@@ -220,6 +237,7 @@ void launch_tensor(Context& c, const u64* a, const u64* b, u64* d, int batch, lo
 // ------------------------------------------------------------------------------------------------ exact base conversion
 //  y_i = x_i*(S/q_i)^-1 mod q_i ; v = floor(sum double(y_i)/double(q_i)) ;
 // out_j = sum_i y_i*(S/q_i) - v*S mod p_j   [centered: x+floor(S/2) in, -floor(S/2) out]
+#define LSA_BC_TGT_PER_BLOCK 7
 struct BaseConvArgs {
     const BaseConvConsts* k;
     const ModDev* mods;
@@ -256,7 +274,10 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
         }
     }
     const int v0 = (int)(u64)vf0, v1 = (int)(u64)vf1;
-    for (int j = 0; j < nd; j++) {
+    // targets are split over blockIdx.z (each block recomputes the cheap y_i/v and converts LSA_BC_TGT_PER_BLOCK targets)
+    const int j0 = blockIdx.z * LSA_BC_TGT_PER_BLOCK;
+    const int j1 = min(nd, j0 + LSA_BC_TGT_PER_BLOCK);
+    for (int j = j0; j < j1; j++) {
         const ModDev m = g.mods[K.dst_mod[j]];
         u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0, r0 = 0, r1 = 0;
 #pragma unroll
@@ -297,7 +318,8 @@ void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows
     g.logn = c.logn;
     g.rows = rows;
     ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns + k->nd), s);
-    hipLaunchKernelGGL(k_baseconv, dim3((unsigned)(c.n / (2 * TPB)), (unsigned)batch), dim3(TPB), 0, s, g);
+    const unsigned gz = (unsigned)((k->nd + LSA_BC_TGT_PER_BLOCK - 1) / LSA_BC_TGT_PER_BLOCK);
+    hipLaunchKernelGGL(k_baseconv, dim3((unsigned)(c.n / (2 * TPB)), (unsigned)batch, gz), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
 

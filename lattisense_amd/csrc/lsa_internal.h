@@ -74,7 +74,12 @@ struct Context {
     u64* d_psi = nullptr;
     u64* d_psiinv = nullptr;
     u64* d_scale = nullptr;
+    double* d_psi_d = nullptr;      // FP64-engine copies of the twiddle tables
+    double* d_psiinv_d = nullptr;
+    double* d_scale_d = nullptr;
+    int fp64_ntt = 1;               // use the FP64 butterfly engine for limbs with q < 2^47
     int tile_batch = 0;
+    int ntt_chunk_mib = 0;          // >0: two-pass NTTs run pass A+B per chunk of this many MiB (Infinity-Cache reuse)
 
     // sampled HIP-event timing of kernel launches (bench.py roofline leg); off unless lsa_profile_begin was called
     struct ProfSample {

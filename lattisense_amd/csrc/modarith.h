@@ -27,9 +27,50 @@ struct ModDev {
     u64 r1;     // 2^64 mod q      (Montgomery one)
 };
 
+// ---- 64x64 multiplies built explicitly from 32-bit halves.  Each line below is one v_mad_u64_u32 (32x32+64 -> 64) or
+// v_mul_hi/lo_u32; hipcc's own lowering of `__umul64hi(a,b)` next to `a*b` recomputes the partial products
+// (measured: ~20 multiplier ops per Montgomery multiply instead of the 11 written here; profiles/ntt_r1a).
+struct U128 {
+    u64 hi, lo;
+};
+LSA_HD U128 mul_wide(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 al = (u32)a, ah = (u32)(a >> 32), bl = (u32)b, bh = (u32)(b >> 32);
+    const u64 p0 = (u64)al * bl;
+    const u64 p1 = (u64)ah * bl + (p0 >> 32);
+    const u64 p2 = (u64)al * bh + (u32)p1;
+    const u64 p3 = (u64)ah * bh + ((p1 >> 32) + (p2 >> 32));
+    U128 r;
+    r.hi = p3;
+    r.lo = (p2 << 32) | (u32)p0;
+    return r;
+#else
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    U128 r;
+    r.hi = (u64)(p >> 64);
+    r.lo = (u64)p;
+    return r;
+#endif
+}
+// low 64 bits of a*b: one mad + two 32-bit low multiplies
+LSA_HD u64 mul_lo64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 al = (u32)a, ah = (u32)(a >> 32), bl = (u32)b, bh = (u32)(b >> 32);
+    const u64 p0 = (u64)al * bl;
+    const u32 hi = (u32)(p0 >> 32) + al * bh + ah * bl;
+    return ((u64)hi << 32) | (u32)p0;
+#else
+    return a * b;
+#endif
+}
+// high 64 bits of a*b
 LSA_HD u64 mulhi64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, b);
+    const u32 al = (u32)a, ah = (u32)(a >> 32), bl = (u32)b, bh = (u32)(b >> 32);
+    const u32 c0 = __umulhi(al, bl);
+    const u64 p1 = (u64)ah * bl + c0;
+    const u64 p2 = (u64)al * bh + (u32)p1;
+    return (u64)ah * bh + ((p1 >> 32) + (p2 >> 32));
 #else
     return (u64)(((unsigned __int128)a * b) >> 64);
 #endif
@@ -37,13 +78,14 @@ LSA_HD u64 mulhi64(u64 a, u64 b) {
 
 // REDC of the 128-bit value (hi,lo) < q*2^64  ->  [0, 2q)   ("lazy": caller reduces when it must)
 LSA_HD u64 mont_redc_lazy(u64 hi, u64 lo, u64 q, u64 qinv) {
-    u64 m = lo * qinv;
-    u64 t = mulhi64(m, q);
+    const u64 m = mul_lo64(lo, qinv);
+    const u64 t = mulhi64(m, q);
     return hi - t + q;
 }
 // a*b*2^-64 mod q in [0,2q); requires a*b < q*2^64 (e.g. a < 2^63, b < q)
 LSA_HD u64 mont_mul_lazy(u64 a, u64 b, u64 q, u64 qinv) {
-    return mont_redc_lazy(mulhi64(a, b), a * b, q, qinv);
+    const U128 p = mul_wide(a, b);
+    return mont_redc_lazy(p.hi, p.lo, q, qinv);
 }
 LSA_HD u64 csub(u64 a, u64 q) { return a >= q ? a - q : a; }
 // a*b*2^-64 mod q in [0,q)
@@ -58,9 +100,9 @@ LSA_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
 
 // 128-bit accumulate helper: (hi,lo) += a*b
 LSA_HD void mac128(u64& hi, u64& lo, u64 a, u64 b) {
-    u64 pl = a * b, ph = mulhi64(a, b);
-    lo += pl;
-    hi += ph + (lo < pl ? 1 : 0);
+    const U128 p = mul_wide(a, b);
+    lo += p.lo;
+    hi += p.hi + (lo < p.lo ? 1 : 0);
 }
 // x mod q for arbitrary 64-bit x and q > 2^32-ish chain primes of any size: via Montgomery (x*R^-1 then *R^2)
 LSA_HD u64 reduce_u64(u64 x, const ModDev& m) {

@@ -17,13 +17,25 @@
 //   * blockIdx -> (limb, tile, batch) with batch fastest: co-resident workgroups share one prime's twiddle slice, which
 //     therefore stays in L1/L2 (twiddles are excluded from the algorithmic byte count for exactly that reason).
 //
-// Values are kept lazily in [0,4q) inside a pass (q < 2^61) and fully reduced on the final store.
+// Two butterfly engines, chosen per workgroup from the limb's modulus (results are the same canonical residues):
+//   INT  (any q < 2^61): Montgomery radix 2^64 on v_mad_u64_u32 chains, Harvey-lazy values in [0,4q);
+//   FP64 (q < 2^47, i.e. most CKKS chain primes): every butterfly is 6 double-precision ops
+//         h = v*w ; l = fma(v,w,-h) ; c = rndne(h/q) ; d = fma(-c,q,h) ; t = d + l     (all exact, |t| < 1.1 q)
+//     — the kernel is VALU-issue bound on the quarter-rate integer multiplier (rocprof: profiles/ntt_r1a_*), and
+//     v_fma_f64 issues at 4x the rate of v_mad_u64_u32.  Exactness: operands are integers of magnitude < 2^51,
+//     h+l is the exact product (FMA error-free transformation), |h/q| < 2^51 keeps c within 1 of the true quotient, so
+//     d and d+l are integers below 2^53 and therefore exact.  A forward pass of <= 9 stages needs no reduction
+//     (growth <= 1.1q per stage); the inverse reduces once per sub-pass (sums double per stage).
 #pragma once
 #include "modarith.h"
 
 #define LSA_NTT_THREADS 256
 #define LSA_MAX_PERIOD 192
 #define LSA_ROW_SKIP 0xFF
+#define LSA_FP64_MAX_BITS 47
+#ifndef LSA_NTT_MAX_RHO
+#define LSA_NTT_MAX_RHO 4   // largest radix exponent of a sub-pass (2^rho points per thread in VGPRs)
+#endif
 
 struct NttPassArgs {
     const u64* src;       // batch base (may equal dst)
@@ -35,10 +47,13 @@ struct NttPassArgs {
     const ModDev* mods;   // [nmod]
     const u64* tw;        // [nmod][N] Montgomery-form psi^{brv(x)} (forward) or psi^{-brv(x)} (inverse)
     const u64* scale;     // [nmod][2] inverse only: {N^-1 * R, psiinv[1] * N^-1 * R}
+    const double* twd;    // [nmod][N] the same twiddles as plain doubles (FP64 engine)
+    const double* scaled; // [nmod][2]
     int logn, s_lo, mu, lambda, tau;
     int inverse;          // 0 forward, 1 inverse
     int apply_scale;      // inverse: this pass contains global stage 0 -> fold N^-1
     int final_reduce;     // store fully reduced [0,q)
+    int allow_fp64;       // 0 forces the integer engine for every limb
     int period;           // row r uses modulus mod_of[r % period]
     unsigned char mod_of[LSA_MAX_PERIOD];
 };
@@ -49,8 +64,9 @@ LSA_HD int lds_words(int tau) { return (1 << tau) + (1 << (tau - 4)) + 16; }
 struct NttBlockCtx {
     long long base_src;   // element offset of this (batch,row) limb in src
     long long base_dst;   // ... in dst
-    int tile;         // tile index inside the limb
-    int mod;          // modulus index
+    int tile;             // tile index inside the limb
+    int mod;              // modulus index
+    int fp;               // 1: FP64 engine
 };
 
 LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
@@ -63,6 +79,8 @@ LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
     c.base_src = (long long)b * a.src_stride + ((long long)row << a.logn);
     c.base_dst = (long long)b * a.dst_stride + ((long long)row << a.logn);
     c.mod = a.mod_of[row % a.period];
+    c.fp = 0;
+    if (c.mod != LSA_ROW_SKIP) c.fp = a.allow_fp64 && (a.mods[c.mod].q >> LSA_FP64_MAX_BITS) == 0 && a.mu <= 9;
     return c;
 }
 
@@ -84,6 +102,36 @@ LSA_HD int ntt_hi_index(const NttPassArgs& a, int tile, int l) {
     return tile >> (lo_bits - a.lambda);
 }
 
+// ---- FP64 engine primitives (all results exact, see header)
+LSA_HD double d_from_bits(u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)b);
+#else
+    double d;
+    __builtin_memcpy(&d, &b, 8);
+    return d;
+#endif
+}
+LSA_HD u64 d_to_bits(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u64)__double_as_longlong(d);
+#else
+    u64 b;
+    __builtin_memcpy(&b, &d, 8);
+    return b;
+#endif
+}
+// v*w mod q as an integer-valued double in (-1.1q, 1.1q); |v| < 2^51, 0 <= w < q < 2^47
+LSA_HD double fp_modmul(double v, double w, double q, double qinv) {
+    const double h = v * w;
+    const double l = __builtin_fma(v, w, -h);
+    const double c = __builtin_rint(h * qinv);
+    const double d = __builtin_fma(-c, q, h);
+    return d + l;
+}
+// x mod q into [-q/2-1, q/2+1] for |x| < 2^53
+LSA_HD double fp_reduce(double x, double q, double qinv) { return __builtin_fma(-__builtin_rint(x * qinv), q, x); }
+
 // phase 0: global -> LDS (2 elements = 16 B per lane per step)
 LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     const u64* g = a.src + bc.base_src;
@@ -91,14 +139,21 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
     for (int i = tid; i < half; i += LSA_NTT_THREADS) {
         int l = 2 * i;
         int x = ntt_global_index(a, bc.tile, l);
+        u64 v0, v1;
 #if defined(__HIP_DEVICE_COMPILE__)
         const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g + x);
-        lds[lds_addr(l)] = v.x;
-        lds[lds_addr(l + 1)] = v.y;
+        v0 = v.x;
+        v1 = v.y;
 #else
-        lds[lds_addr(l)] = g[x];
-        lds[lds_addr(l + 1)] = g[x + 1];
+        v0 = g[x];
+        v1 = g[x + 1];
 #endif
+        if (bc.fp) {  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact as doubles
+            v0 = d_to_bits((double)v0);
+            v1 = d_to_bits((double)v1);
+        }
+        lds[lds_addr(l)] = v0;
+        lds[lds_addr(l + 1)] = v1;
     }
 }
 
@@ -106,12 +161,21 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
 LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64* lds) {
     u64* g = a.dst + bc.base_dst;
     const u64 q = a.mods[bc.mod].q;
+    const double qd = (double)q, qinvd = 1.0 / qd;
     int half = 1 << (a.tau - 1);
     for (int i = tid; i < half; i += LSA_NTT_THREADS) {
         int l = 2 * i;
         int x = ntt_global_index(a, bc.tile, l);
         u64 v0 = lds[lds_addr(l)], v1 = lds[lds_addr(l + 1)];
-        if (a.final_reduce) {
+        if (bc.fp) {  // always canonical on store: the next pass reloads exact small integers
+            double r0 = fp_reduce(d_from_bits(v0), qd, qinvd), r1 = fp_reduce(d_from_bits(v1), qd, qinvd);
+            if (r0 < 0) r0 += qd;
+            if (r1 < 0) r1 += qd;
+            v0 = (u64)r0;
+            v1 = (u64)r1;
+            v0 = csub(v0, q);
+            v1 = csub(v1, q);
+        } else if (a.final_reduce) {
             v0 = csub(csub(v0, 2 * q), q);
             v1 = csub(csub(v1, 2 * q), q);
         }
@@ -127,7 +191,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     }
 }
 
-// One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass.
+// One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass — integer (Montgomery) engine.
 template <int RHO>
 LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
@@ -187,6 +251,64 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
     }
 }
 
+// The same sub-pass on the FP64 engine: LDS holds integer-valued doubles.
+template <int RHO>
+LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
+    constexpr int E = 1 << RHO;
+    const double q = (double)a.mods[bc.mod].q, qinv = 1.0 / q;
+    const double* tw = a.twd + ((long long)bc.mod << a.logn);
+    const int beta0 = a.lambda + a.mu - sig0 - RHO;
+    const int ngroups = 1 << (a.tau - RHO);
+    for (int gid = tid; gid < ngroups; gid += LSA_NTT_THREADS) {
+        int lbase = ((gid >> beta0) << (beta0 + RHO)) | (gid & ((1 << beta0) - 1));
+        double v[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) v[e] = d_from_bits(lds[lds_addr(lbase + (e << beta0))]);
+        int r = (lbase >> a.lambda) & ((1 << a.mu) - 1);
+        int H = ntt_hi_index(a, bc.tile, lbase);
+        int G = (H << sig0) + (r >> (a.mu - sig0));
+        if (!a.inverse) {
+#pragma unroll
+            for (int j = 0; j < RHO; j++) {
+                const int half = E >> (j + 1);
+                const int s = a.s_lo + sig0 + j;
+                const double* twj = tw + (1 << s) + ((long long)G << j);
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if ((e & half) == 0) {
+                        const double T = fp_modmul(v[e + half], twj[e >> (RHO - j)], q, qinv);
+                        const double U = v[e];
+                        v[e] = U + T;          // |.| grows by < 1.1q per stage: <= 10.9q < 2^51 over a 9-stage pass
+                        v[e + half] = U - T;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = RHO - 1; j >= 0; j--) {
+                const int half = E >> (j + 1);
+                const int s = a.s_lo + sig0 + j;
+                const double* twj = tw + (1 << s) + ((long long)G << j);
+                const bool last = a.apply_scale && s == 0;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if ((e & half) == 0) {
+                        const double w = last ? a.scaled[2 * bc.mod + 1] : twj[e >> (RHO - j)];
+                        const double U = v[e], V = v[e + half];
+                        const double S = U + V, D = U - V;   // sums at most double per stage: < 16 * 1.1q inside a sub-pass
+                        v[e] = last ? fp_modmul(S, a.scaled[2 * bc.mod], q, qinv) : S;
+                        v[e + half] = fp_modmul(D, w, q, qinv);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], q, qinv);  // back to |.| <= q/2+1 before the next sub-pass
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) lds[lds_addr(lbase + (e << beta0))] = d_to_bits(v[e]);
+    }
+}
+
 // sub-pass plan: split mu stages into ceil(mu/4) nearly equal radix groups (each <= 4)
 LSA_HD int ntt_plan(int mu, int* rho /*[4]*/) {
     int n = (mu + 3) / 4;
@@ -196,10 +318,31 @@ LSA_HD int ntt_plan(int mu, int* rho /*[4]*/) {
 }
 
 LSA_HD void ntt_phase_sub_dyn(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
+    if (bc.fp) {
+        switch (rho) {
+            case 1: ntt_phase_sub_fp<1>(a, bc, tid, lds, sig0); break;
+            case 2: ntt_phase_sub_fp<2>(a, bc, tid, lds, sig0); break;
+#if LSA_NTT_MAX_RHO >= 4
+            case 3: ntt_phase_sub_fp<3>(a, bc, tid, lds, sig0); break;
+            default: ntt_phase_sub_fp<4>(a, bc, tid, lds, sig0); break;
+#elif LSA_NTT_MAX_RHO == 3
+            default: ntt_phase_sub_fp<3>(a, bc, tid, lds, sig0); break;
+#else
+            default: break;
+#endif
+        }
+        return;
+    }
     switch (rho) {
         case 1: ntt_phase_sub<1>(a, bc, tid, lds, sig0); break;
         case 2: ntt_phase_sub<2>(a, bc, tid, lds, sig0); break;
+#if LSA_NTT_MAX_RHO >= 4
         case 3: ntt_phase_sub<3>(a, bc, tid, lds, sig0); break;
         default: ntt_phase_sub<4>(a, bc, tid, lds, sig0); break;
+#elif LSA_NTT_MAX_RHO == 3
+        default: ntt_phase_sub<3>(a, bc, tid, lds, sig0); break;
+#else
+        default: break;
+#endif
     }
 }

@@ -137,10 +137,12 @@ static void rescale(Context& c, int level, int polys, const u64* in, long long s
 // ------------------------------------------------------------------------------------------------ tiling
 static int pick_tile(const Context& c, size_t rows_per_ct, int batch) {
     if (c.tile_batch > 0) return std::min(c.tile_batch, batch);
-    // keep a tile's intermediates around the size of the 256 MiB Infinity Cache, but at least 1 ciphertext
+    // measured on MI355X (gpurun_out/tile_sweep.log): launches need >= ~2k workgroups each to fill 256 CUs, which at
+    // N=2^16 means ~16 ciphertexts per wave; beyond that nothing is gained and the workspace only grows.
     const size_t bytes_per_ct = rows_per_ct * (size_t)c.n * sizeof(u64);
-    size_t tb = (192ull << 20) / std::max<size_t>(bytes_per_ct, 1);
+    size_t tb = (2ull << 30) / std::max<size_t>(bytes_per_ct, 1);
     if (tb < 1) tb = 1;
+    if (tb > 64) tb = 64;
     return (int)std::min<size_t>(tb, (size_t)batch);
 }
 

@@ -156,6 +156,9 @@ void HostTables::build(int n_, const std::vector<u64>& moduli) {
     psi.assign(nm * (size_t)n, 0);
     psiinv.assign(nm * (size_t)n, 0);
     scale.assign(nm * 2, 0);
+    psi_d.assign(nm * (size_t)n, 0.0);
+    psiinv_d.assign(nm * (size_t)n, 0.0);
+    scale_d.assign(nm * 2, 0.0);
     for (size_t i = 0; i < nm; i++) {
         const u64 q = mod[i];
         if (q >> 61) throw std::runtime_error("modulus exceeds 61 bits: " + std::to_string(q));
@@ -179,6 +182,10 @@ void HostTables::build(int n_, const std::vector<u64>& moduli) {
             unsigned x = bit_reverse((unsigned)j, logn);
             t[x] = to_mont_host(pw, q);
             ti[x] = to_mont_host(pwi, q);
+            if ((q >> 53) == 0) {  // exactly representable; only consumed when q < 2^47
+                psi_d[i * (size_t)n + x] = (double)pw;
+                psiinv_d[i * (size_t)n + x] = (double)pwi;
+            }
             pw = mul_mod_host(pw, ps, q);
             pwi = mul_mod_host(pwi, psi_inv, q);
         }
@@ -187,6 +194,10 @@ void HostTables::build(int n_, const std::vector<u64>& moduli) {
         // psiinv[1] = psi^{-brv(1)} = psi^{-n/2}
         u64 w1 = pow_mod(psi_inv, (u64)n / 2, q);
         scale[2 * i + 1] = to_mont_host(mul_mod_host(w1, ninv, q), q);
+        if ((q >> 53) == 0) {
+            scale_d[2 * i] = (double)ninv;
+            scale_d[2 * i + 1] = (double)mul_mod_host(w1, ninv, q);
+        }
     }
 }
 

@@ -24,6 +24,8 @@ struct HostTables {
     std::vector<u64> psi;       // [nmod][n]  psi^{brv(x)} * 2^64 mod q
     std::vector<u64> psiinv;    // [nmod][n]  psi^{-brv(x)} * 2^64 mod q
     std::vector<u64> scale;     // [nmod][2]  {n^-1 * 2^64, psiinv[1] * n^-1 * 2^64} mod q
+    // the same tables as plain integer-valued doubles for the FP64 butterfly engine (used for q < 2^47 only)
+    std::vector<double> psi_d, psiinv_d, scale_d;
     void build(int n_, const std::vector<u64>& moduli);
 };
 

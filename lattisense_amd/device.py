@@ -84,6 +84,9 @@ class DeviceContext:
     def set_tile_batch(self, tb):
         check(lib().lsa_set_tile_batch(self.h, tb))
 
+    def set_fp64_ntt(self, enable):
+        check(lib().lsa_set_fp64_ntt(self.h, int(enable)))
+
     # ---- keys
     def upload_key(self, compact, key_level):
         compact = np.ascontiguousarray(compact, dtype=np.uint64)

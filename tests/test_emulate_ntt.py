@@ -1,5 +1,6 @@
 """Replays the HIP NTT kernel's phase functions on the CPU (one simulated thread at a time) and checks them
-bit-exactly against the oracle.  This validates the kernel's tile/sub-pass/twiddle indexing without a GPU;
+bit-exactly against the oracle, for both butterfly engines (integer Montgomery; exact FP64-FMA for q < 2^47).
+This validates the kernel's tile/sub-pass/twiddle indexing and the FP64 exactness argument without a GPU;
 the real kernel is checked on the GPU in tests/test_gpu_*.py."""
 import ctypes
 import os
@@ -26,28 +27,46 @@ def emu():
     return L
 
 
-def run(emu, n, mods, data, rows, mod_of, inverse, tau):
+def run(emu, n, mods, data, rows, mod_of, inverse, tau, fp64=1):
     batch = data.shape[0]
     arr = (ctypes.c_uint64 * len(mods))(*mods)
     mo = (ctypes.c_ubyte * len(mod_of))(*mod_of)
     emu.lsa_emu_ntt(ctypes.c_int(n), arr, len(mods), data.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
-                    batch, ctypes.c_longlong(rows * n), rows, mo, len(mod_of), int(inverse), tau)
+                    batch, ctypes.c_longlong(rows * n), rows, mo, len(mod_of), int(inverse), tau, int(fp64))
+
+
+def _check(emu, logn, tau, mods, fp64):
+    n = 1 << logn
+    o = Oracle(n, mods, [], 0)
+    rng = np.random.default_rng(logn)
+    batch, rows = 2, len(mods)
+    data = np.stack([np.stack([rng.integers(0, mods[r], size=n, dtype=np.uint64) for r in range(rows)])
+                     for _ in range(batch)])
+    data[0, :, 0] = 0
+    data[0, :, 1] = np.array([m - 1 for m in mods], dtype=np.uint64)   # extreme residues
+    data[1, :, :] = np.array([m - 1 for m in mods], dtype=np.uint64)[:, None]  # all-max limb: worst-case growth
+    want = np.stack([np.stack([o.ntt(r, data[b, r]) for r in range(rows)]) for b in range(batch)])
+    got = data.copy()
+    run(emu, n, mods, got, rows, list(range(rows)), 0, tau, fp64)
+    assert np.array_equal(got, want)
+    run(emu, n, mods, got, rows, list(range(rows)), 1, tau, fp64)
+    assert np.array_equal(got, data)
 
 
 # (logn, tau_max): single pass, two passes with several (mu_a, mu_b) splits incl. odd logn
 @pytest.mark.parametrize("logn,tau", [(8, 12), (10, 12), (12, 12), (13, 12), (14, 12), (11, 8), (13, 10), (15, 12)])
-def test_emulated_kernel_matches_oracle(emu, logn, tau):
-    n = 1 << logn
-    mods = [m for m in (params.CKKS_BOOTSTRAP_65536["q"][:2] + params.CKKS_BOOTSTRAP_65536["p"][:1])]
-    o = Oracle(n, mods, [], 0)
-    rng = np.random.default_rng(logn)
-    batch, rows = 2, 3
-    data = np.stack([np.stack([rng.integers(0, mods[r], size=n, dtype=np.uint64) for r in range(rows)])
-                     for _ in range(batch)])
-    data[0, 0, :4] = [0, mods[0] - 1, 1, mods[0] - 2]
-    want = np.stack([np.stack([o.ntt(r, data[b, r]) for r in range(rows)]) for b in range(batch)])
-    got = data.copy()
-    run(emu, n, mods, got, rows, [0, 1, 2], 0, tau)
-    assert np.array_equal(got, want)
-    run(emu, n, mods, got, rows, [0, 1, 2], 1, tau)
-    assert np.array_equal(got, data)
+def test_integer_engine_matches_oracle(emu, logn, tau):
+    B = params.CKKS_BOOTSTRAP_65536
+    _check(emu, logn, tau, B["q"][:2] + B["p"][:1], fp64=0)   # 60-, 40-, 61-bit
+
+
+@pytest.mark.parametrize("logn,tau", [(9, 12), (12, 12), (13, 12), (14, 12), (15, 12), (13, 10)])
+def test_fp64_engine_matches_oracle(emu, logn, tau):
+    # 46/45-bit (largest primes the FP64 engine accepts in the default chains), 40- and 39-bit, plus a 60-bit limb that
+    # must keep using the integer engine inside the same launch
+    D = params.CKKS_DEFAULT[65536]
+    B = params.CKKS_BOOTSTRAP_65536
+    mods = [D["q"][1], D["q"][3], B["q"][1], B["q"][10], B["q"][0]]
+    assert max(m.bit_length() for m in mods[:4]) <= 46
+    _check(emu, logn, tau, mods, fp64=1)
+    _check(emu, logn, tau, mods, fp64=0)
