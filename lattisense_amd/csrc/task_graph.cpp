@@ -1,0 +1,310 @@
+// task_graph.cpp — loader for mega_ag.json: parsing, ABI-bridge insertion for a device backend, level computation.
+// Behaviour follows mega_ag_runners/mega_ag.cpp:125-657 (see task_graph.h); written for this runtime's level-batched
+// scheduler (top_level drives execution order, bottom_level is kept as the reference's priority).
+#include "task_graph.h"
+
+#include <algorithm>
+#include <queue>
+#include <stdexcept>
+
+namespace {
+
+DataType datum_type_of(const std::string& s) {
+    if (s == "ct" || s == "ct3") return TYPE_CIPHERTEXT;
+    if (s == "pt" || s == "pt_mul" || s == "pt_ringt") return TYPE_PLAINTEXT;
+    if (s == "rlk") return TYPE_RELIN_KEY;
+    if (s == "glk") return TYPE_GALOIS_KEY;
+    if (s == "swk") return TYPE_SWITCH_KEY;
+    throw std::runtime_error("unknown datum type '" + s + "' in mega_ag.json");
+}
+
+OperationType op_type_of(const std::string& s) {
+    static const std::pair<const char*, OperationType> table[] = {
+        {"add", OperationType::ADD},
+        {"sub", OperationType::SUB},
+        {"neg", OperationType::NEGATE},
+        {"mult", OperationType::MULTIPLY},
+        {"relin", OperationType::RELINEARIZE},
+        {"rescale", OperationType::RESCALE},
+        {"drop_level", OperationType::DROP_LEVEL},
+        {"rotate_row", OperationType::ROTATE_ROW},
+        {"rotate_col", OperationType::ROTATE_COL},
+        {"cmp_sum", OperationType::MAC_WO_PARTIAL_SUM},
+        {"cmpac_sum", OperationType::MAC_W_PARTIAL_SUM},
+        {"bootstrap", OperationType::BOOTSTRAP},
+        {"fpga_kernel", OperationType::FPGA_KERNEL},
+    };
+    for (auto& e : table)
+        if (s == e.first) return e.second;
+    throw std::runtime_error("unknown operation type '" + s + "' in mega_ag.json");
+}
+
+bool is_custom_json(const mjson::Value& v) { return v.contains("is_custom") && v["is_custom"].as_bool(); }
+
+}  // namespace
+
+TaskGraph TaskGraph::load_for_gpu(const std::string& json_path) {
+    TaskGraph g;
+    g.parse(json_path);
+    g.insert_bridges();
+    g.assign_processors();
+    g.compute_levels();
+    return g;
+}
+
+void TaskGraph::parse(const std::string& json_path) {
+    mjson::Value root;
+    try {
+        root = mjson::parse_file(json_path);
+    } catch (const std::exception& e) {
+        throw std::runtime_error(std::string("Cannot open MegaAG file ") + json_path + " (" + e.what() + ")");
+    }
+    const std::string& algo_s = root["algorithm"].as_string();
+    if (algo_s == "BFV") algo = ALGO_BFV;
+    else if (algo_s == "CKKS") algo = ALGO_CKKS;
+    else throw std::runtime_error("Unknown algorithm: " + algo_s);
+    parameter = root["parameter"];
+
+    for (auto& kv : root["data"].obj) {
+        const mjson::Value& v = kv.second;
+        DatumNode n;
+        n.index = std::stoull(kv.first);
+        n.id = v["id"].as_string();
+        const std::string& type_s = v["type"].as_string();
+        if (is_custom_json(v)) {
+            DatumNode::CustomProperty cp;
+            cp.type = type_s;
+            if (v.contains("attributes")) cp.attributes = v["attributes"];
+            n.custom_prop = cp;
+        } else {
+            DatumNode::FheProperty fp;
+            fp.level = (int32_t)v["level"].as_int();
+            fp.degree = (int32_t)v["degree"].as_int();
+            fp.is_ntt = v["is_ntt"].as_bool();
+            fp.is_mform = v["is_mform"].as_bool();
+            fp.sp_level = v.contains("sp_level") ? (int32_t)v["sp_level"].as_int() : -1;
+            n.datum_type = datum_type_of(type_s);
+            if (n.datum_type == TYPE_GALOIS_KEY) {
+                DatumNode::FheProperty::ExtraProperty ep;
+                ep.galois_element = (uint32_t)v["galois_element"].as_u64();
+                fp.p = ep;
+            } else if (type_s == "pt_ringt") {
+                DatumNode::FheProperty::ExtraProperty ep;
+                ep.is_ringt = true;
+                fp.p = ep;
+            }
+            n.fhe_prop = fp;
+        }
+        next_data = std::max(next_data, n.index + 1);
+        data.emplace(n.index, std::move(n));
+    }
+
+    for (auto& kv : root["compute"].obj) {
+        const mjson::Value& v = kv.second;
+        ComputeNode c;
+        c.index = std::stoull(kv.first);
+        c.id = v["id"].as_string();
+        const std::string& type_s = v["type"].as_string();
+        if (is_custom_json(v)) {
+            ComputeNode::CustomProperty cp;
+            cp.type = type_s;
+            if (v.contains("attributes")) cp.attributes = v["attributes"];
+            c.custom_prop = cp;
+        } else {
+            ComputeNode::FheProperty fp;
+            fp.op_type = op_type_of(type_s);
+            if (fp.op_type == OperationType::ROTATE_COL) {
+                ComputeNode::FheProperty::ExtraProperty ep;
+                ep.rotation_step = (int32_t)v["step"].as_int();
+                fp.p = ep;
+            } else if (fp.op_type == OperationType::MAC_WO_PARTIAL_SUM || fp.op_type == OperationType::MAC_W_PARTIAL_SUM) {
+                ComputeNode::FheProperty::ExtraProperty ep;
+                ep.sum_cnt = (int32_t)v["sum_cnt"].as_int();
+                fp.p = ep;
+            }
+            c.fhe_prop = fp;
+        }
+        for (auto& e : v["inputs"].arr) c.input_nodes.push_back(&data.at(e.as_u64()));
+        for (auto& e : v["outputs"].arr) c.output_nodes.push_back(&data.at(e.as_u64()));
+        next_compute = std::max(next_compute, c.index + 1);
+        computes.emplace(c.index, std::move(c));
+    }
+    for (auto& kv : computes) {
+        for (auto* d : kv.second.input_nodes) d->successors.push_back(&kv.second);
+        for (auto* d : kv.second.output_nodes) d->predecessors.push_back(&kv.second);
+    }
+    for (auto& e : root["inputs"].arr) {
+        inputs.push_back(e.as_u64());
+        data.at(e.as_u64()).is_input = true;
+    }
+    for (auto& e : root["outputs"].arr) {
+        outputs.push_back(e.as_u64());
+        data.at(e.as_u64()).is_output = true;
+    }
+}
+
+DatumNode& TaskGraph::clone_datum(const DatumNode& src, const std::string& id) {
+    DatumNode n = src;
+    n.index = next_data++;
+    n.id = id;
+    n.is_input = n.is_output = false;
+    n.predecessors.clear();
+    n.successors.clear();
+    auto it = data.emplace(n.index, std::move(n)).first;
+    return it->second;
+}
+
+void TaskGraph::link_bridge(OperationType op, const std::string& id, DatumNode* in, DatumNode* out) {
+    ComputeNode c;
+    c.index = next_compute++;
+    c.id = id;
+    ComputeNode::FheProperty fp;
+    fp.op_type = op;
+    c.fhe_prop = fp;
+    c.input_nodes.push_back(in);
+    c.output_nodes.push_back(out);
+    auto it = computes.emplace(c.index, std::move(c)).first;
+    in->successors.push_back(&it->second);
+    out->predecessors.push_back(&it->second);
+}
+
+// For every original datum decide where its bytes natively live (caller handle vs. device) and splice in
+// export->load (host to device) or store->import (device to host) chains where a consumer lives on the other side.
+void TaskGraph::insert_bridges() {
+    std::vector<NodeIndex> originals;
+    for (auto& kv : data) originals.push_back(kv.first);
+    std::sort(originals.begin(), originals.end());
+
+    auto retarget_inputs = [](std::vector<ComputeNode*>& consumers, DatumNode& from, DatumNode& to) {
+        for (ComputeNode* c : consumers) {
+            for (auto& in : c->input_nodes)
+                if (in == &from) in = &to;
+            to.successors.push_back(c);
+        }
+    };
+
+    for (NodeIndex idx : originals) {
+        DatumNode& d = data.at(idx);
+        const bool host_native = d.is_input || (!d.predecessors.empty() && d.predecessors[0]->custom_prop.has_value());
+        std::vector<ComputeNode*> dev_consumers, host_consumers;
+        for (ComputeNode* c : d.successors) (c->custom_prop ? host_consumers : dev_consumers).push_back(c);
+        const std::string tag = std::to_string(idx);
+
+        if (d.is_input && d.custom_prop) {  // custom input data: only made concrete on the host
+            DatumNode& conc = clone_datum(d, d.id + "_concrete");
+            std::vector<ComputeNode*> all = d.successors;
+            d.successors.clear();
+            retarget_inputs(all, d, conc);
+            link_bridge(OperationType::EXPORT_TO_ABI, "export_to_abi_" + tag, &d, &conc);
+            continue;
+        }
+        if (host_native && !dev_consumers.empty()) {  // handle -> C struct -> device
+            DatumNode& cs = clone_datum(d, d.id + "_c_struct_h2d");
+            DatumNode& dev = clone_datum(d, d.id + "_gpu");
+            d.successors = host_consumers;
+            retarget_inputs(dev_consumers, d, dev);
+            link_bridge(OperationType::EXPORT_TO_ABI, "export_to_abi_" + tag, &d, &cs);
+            link_bridge(OperationType::LOAD_TO_BACKEND, "load_to_gpu_" + tag, &cs, &dev);
+        }
+        if (!host_native && (!host_consumers.empty() || d.is_output)) {  // device -> C struct -> handle
+            DatumNode& dev = clone_datum(d, d.id + "_gpu");
+            DatumNode& cs = clone_datum(d, d.id + "_c_struct_d2h");
+            // device producers now write the device datum
+            for (ComputeNode* p : d.predecessors) {
+                for (auto& out : p->output_nodes)
+                    if (out == &d) out = &dev;
+                dev.predecessors.push_back(p);
+            }
+            d.predecessors.clear();
+            d.successors.clear();
+            retarget_inputs(dev_consumers, d, dev);
+            link_bridge(OperationType::STORE_FROM_BACKEND, "store_from_gpu_" + tag, &dev, &cs);
+            if (d.is_output) {
+                link_bridge(OperationType::IMPORT_FROM_ABI, "import_from_abi_" + tag, &cs, &d);
+                retarget_inputs(host_consumers, d, d);  // custom consumers of an output read the imported handle
+            } else {
+                DatumNode& h = clone_datum(d, d.id + "_handle");
+                link_bridge(OperationType::IMPORT_FROM_ABI, "import_from_abi_" + tag, &cs, &h);
+                retarget_inputs(host_consumers, d, h);
+            }
+        }
+        if (host_native && d.is_output && !d.is_input) {  // produced by a custom node and returned to the caller
+            DatumNode& conc = clone_datum(d, d.id + "_concrete");
+            for (ComputeNode* p : d.predecessors) {
+                for (auto& out : p->output_nodes)
+                    if (out == &d) out = &conc;
+                conc.predecessors.push_back(p);
+            }
+            d.predecessors.clear();
+            link_bridge(OperationType::IMPORT_FROM_ABI, "import_from_abi_" + tag, &conc, &d);
+        }
+    }
+}
+
+void TaskGraph::assign_processors() {
+    for (auto& kv : computes) {
+        ComputeNode& c = kv.second;
+        if (c.custom_prop) c.on_cpu = true;
+        else c.on_cpu = c.op() == OperationType::EXPORT_TO_ABI || c.op() == OperationType::IMPORT_FROM_ABI;
+    }
+}
+
+// top_level = longest path from a source, bottom_level = longest path to a sink (Kahn, O(V+E)); priority = bottom_level
+void TaskGraph::compute_levels() {
+    std::unordered_map<NodeIndex, int> indeg, outdeg;
+    for (auto& kv : computes) {
+        ComputeNode& c = kv.second;
+        c.sched_meta = {};
+        int in = 0, out = 0;
+        for (auto* d : c.input_nodes) in += (int)d->predecessors.size();
+        for (auto* d : c.output_nodes) out += (int)d->successors.size();
+        indeg[c.index] = in;
+        outdeg[c.index] = out;
+    }
+    std::queue<ComputeNode*> q;
+    for (auto& kv : computes)
+        if (indeg[kv.first] == 0) q.push(&kv.second);
+    size_t seen = 0;
+    while (!q.empty()) {
+        ComputeNode* u = q.front();
+        q.pop();
+        seen++;
+        for (auto* d : u->output_nodes)
+            for (ComputeNode* v : d->successors) {
+                v->sched_meta.top_level = std::max(v->sched_meta.top_level, u->sched_meta.top_level + 1);
+                if (--indeg[v->index] == 0) q.push(v);
+            }
+    }
+    if (seen != computes.size()) throw std::runtime_error("task graph has a cycle");
+    for (auto& kv : computes)
+        if (outdeg[kv.first] == 0) q.push(&kv.second);
+    while (!q.empty()) {
+        ComputeNode* v = q.front();
+        q.pop();
+        for (auto* d : v->input_nodes)
+            for (ComputeNode* u : d->predecessors) {
+                u->sched_meta.bottom_level = std::max(u->sched_meta.bottom_level, v->sched_meta.bottom_level + 1);
+                if (--outdeg[u->index] == 0) q.push(u);
+            }
+    }
+    max_top_level = 0;
+    for (auto& kv : computes) {
+        kv.second.priority = kv.second.sched_meta.bottom_level;
+        max_top_level = std::max(max_top_level, kv.second.sched_meta.top_level);
+    }
+}
+
+void TaskGraph::bind_bridge_executors(const ExecutorFunc& abi_export, const ExecutorFunc& abi_import) {
+    for (auto& kv : computes) {
+        if (kv.second.op() == OperationType::EXPORT_TO_ABI) kv.second.executor = abi_export;
+        else if (kv.second.op() == OperationType::IMPORT_FROM_ABI) kv.second.executor = abi_import;
+    }
+}
+
+void TaskGraph::bind_custom_executors(const std::unordered_map<std::string, ExecutorFunc>& custom) {
+    for (auto& kv : computes) {
+        if (!kv.second.custom_prop) continue;
+        auto it = custom.find(kv.second.custom_prop->type);
+        if (it != custom.end()) kv.second.executor = it->second;
+    }
+}

@@ -1,0 +1,145 @@
+// task_graph.h — in-memory task graph ("MegaAG") of one compiled FHE task, and the executor interface.
+//
+// Interface restated from the reference so that callers' executors keep their shape:
+//   ExecutorFunc / ExecutionContext        mega_ag_runners/mega_ag.h:40-66
+//   OperationType (graph + bridge ops)     mega_ag_runners/mega_ag.h:68-91, type strings mega_ag.cpp:27-47
+//   DatumNode / ComputeNode properties     mega_ag_runners/mega_ag.h:99-177
+// The loader (task_graph.cpp) follows MegaAG::load / from_json / insert_backend_abi_bridge_nodes /
+// compute_properties (mega_ag.cpp:125-657) in behaviour; the implementation is this project's own.
+// NOTE: std::function / std::any / these structs cross the `void*` executor boundary, so an
+// in-tree build of the reference must compile this runtime against the same headers and libstdc++ ABI.
+#pragma once
+#include <any>
+#include <cstdint>
+#include <functional>
+#include <optional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lattisense_task.h"
+#include "mini_json.h"
+
+using NodeIndex = uint64_t;
+struct ComputeNode;
+
+struct ExecutionContext {
+    std::any context;                  // backend-specific arithmetic context (empty for CPU-side bridge/custom nodes here)
+    std::vector<std::any> other_args;  // e.g. the pre-allocated output handle (void*) for IMPORT_FROM_ABI
+    template <typename T> T* get_arithmetic_context() {
+        auto* p = std::any_cast<T*>(&context);
+        return p ? *p : nullptr;
+    }
+    template <typename T> T* get_other_arg(size_t index = 0) {
+        if (index >= other_args.size() || !other_args[index].has_value()) return nullptr;
+        return std::any_cast<T*>(other_args[index]);
+    }
+};
+
+using ExecutorFunc = std::function<void(ExecutionContext& ctx, const std::unordered_map<NodeIndex, std::any>& inputs,
+                                        std::any& output, const ComputeNode& self)>;
+
+enum class OperationType {
+    UNKNOWN,
+    ADD,
+    SUB,
+    NEGATE,
+    MULTIPLY,
+    RELINEARIZE,
+    RESCALE,
+    DROP_LEVEL,
+    ROTATE_COL,
+    ROTATE_ROW,
+    MAC_WO_PARTIAL_SUM,
+    MAC_W_PARTIAL_SUM,
+    BOOTSTRAP,
+    FPGA_KERNEL,
+    EXPORT_TO_ABI,       // caller handle  -> C struct      (caller's executor, CPU)
+    IMPORT_FROM_ABI,     // C struct       -> caller handle (caller's executor, CPU)
+    LOAD_TO_BACKEND,     // C struct       -> device datum  (this library)
+    STORE_FROM_BACKEND,  // device datum   -> C struct      (this library)
+};
+
+struct DatumNode {
+    NodeIndex index = 0;
+    std::string id;
+    std::vector<ComputeNode*> predecessors;
+    std::vector<ComputeNode*> successors;
+    bool is_input = false;
+    bool is_output = false;
+    DataType datum_type = TYPE_CUSTOM;
+    struct FheProperty {
+        int32_t level = 0;
+        int32_t degree = 0;
+        bool is_ntt = false;
+        bool is_mform = false;
+        struct ExtraProperty {
+            bool is_ringt = false;
+            bool is_compressed = false;
+            uint32_t galois_element = 0;
+        };
+        std::optional<ExtraProperty> p;
+        int32_t sp_level = 0;
+    };
+    std::optional<FheProperty> fhe_prop;
+    struct CustomProperty {
+        std::string type;
+        mjson::Value attributes;
+    };
+    std::optional<CustomProperty> custom_prop;
+};
+
+struct ComputeNode {
+    NodeIndex index = 0;
+    std::string id;
+    std::vector<DatumNode*> input_nodes;
+    std::vector<DatumNode*> output_nodes;
+    ExecutorFunc executor;   // CPU-side nodes (export / import / custom); backend nodes are dispatched by op type
+    bool on_cpu = false;
+    int priority = 0;
+    struct ScheduleMeta {
+        int top_level = 0;
+        int bottom_level = 0;
+    };
+    ScheduleMeta sched_meta;
+    struct FheProperty {
+        OperationType op_type = OperationType::UNKNOWN;
+        struct ExtraProperty {
+            int32_t rotation_step = 0;
+            int32_t sum_cnt = 0;
+        };
+        std::optional<ExtraProperty> p;
+    };
+    std::optional<FheProperty> fhe_prop;
+    struct CustomProperty {
+        std::string type;
+        mjson::Value attributes;
+    };
+    std::optional<CustomProperty> custom_prop;
+
+    OperationType op() const { return fhe_prop ? fhe_prop->op_type : OperationType::UNKNOWN; }
+};
+
+struct TaskGraph {
+    std::unordered_map<NodeIndex, DatumNode> data;      // node addresses are stable (unordered_map never moves values)
+    std::unordered_map<NodeIndex, ComputeNode> computes;
+    std::vector<NodeIndex> inputs, outputs;
+    mjson::Value parameter;
+    Algo algo = ALGO_BFV;
+    int max_top_level = 0;
+
+    // parse <path>, insert the ABI bridge nodes for a device backend, compute levels and priorities
+    static TaskGraph load_for_gpu(const std::string& json_path);
+
+    void bind_bridge_executors(const ExecutorFunc& abi_export, const ExecutorFunc& abi_import);
+    void bind_custom_executors(const std::unordered_map<std::string, ExecutorFunc>& custom);
+
+private:
+    void parse(const std::string& json_path);
+    void insert_bridges();
+    void link_bridge(OperationType op, const std::string& id, DatumNode* in, DatumNode* out);
+    void assign_processors();
+    void compute_levels();
+    NodeIndex next_data = 0, next_compute = 0;
+    DatumNode& clone_datum(const DatumNode& src, const std::string& id);
+};

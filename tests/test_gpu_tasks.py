@@ -1,0 +1,212 @@
+"""End-to-end through the drop-in task boundary (create/bind/run/release_fhe_gpu_task, wrapper.h:67-85) with the native
+front-end: compiled task graphs (fixtures emitted by the reference's frontend) run on the GPU and are compared
+bit-exactly with the CPU oracle applied node by node, plus the reference's message-level assertion."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.gpu_util import need_gpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TASKS = os.path.join(ROOT, "tests", "golden", "tasks")
+N_OP = 4
+
+
+def _load(name):
+    from oracle.client import Client
+    from oracle.pyoracle import Oracle
+    g = json.load(open(os.path.join(TASKS, name, "mega_ag.json")))
+    P = g["parameter"]
+    o = Oracle(P["n"], P["q"][: P["max_level"] + 1], P["p"], P.get("t", 0))
+    return g, P, o, Client(o, seed=len(name))
+
+
+def _task(name):
+    from lattisense_amd.task import FheTaskGpu
+    return FheTaskGpu(os.path.join(TASKS, name))
+
+
+def _ckks_inputs(c, n, lvl, count, seed):
+    rng = np.random.default_rng(seed)
+    msgs = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(count)]
+    return msgs, [c.ckks_encrypt(m, lvl, float(2 ** 34)) for m in msgs]
+
+
+def test_ckks_cmc_relin_rescale_task():
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, KeySwitchKey
+    from oracle.client import mean_precision_bits
+    g, P, o, c = _load("ckks_n4096_cmc_relin_rescale")
+    n, lvl = P["n"], 4
+    xm, xs = _ckks_inputs(c, n, lvl, N_OP, 1)
+    ym, ys = _ckks_inputs(c, n, lvl, N_OP, 2)
+    rlk = c.gen_relin_key(lvl)
+    t = _task("ckks_n4096_cmc_relin_rescale")
+    zs = [Ciphertext.empty(1, lvl - 1, n) for _ in range(N_OP)]
+    seen = []
+    ns = t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
+                Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("out_z_list", zs)],
+               progress_cb=lambda d, tot: seen.append((d, tot)))
+    assert ns > 0 and seen and seen[-1][0] == seen[-1][1] == t.counts()["compute"]
+    st = t.last_run_stats()
+    assert st["gpu_nodes"] == 3 * N_OP and st["gpu_batches"] == 3      # 12 operator nodes -> 3 batched launches
+    for i in range(N_OP):
+        want = o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk, lvl)
+        assert np.array_equal(zs[i].data, want)
+        re, im = mean_precision_bits(xm[i] * ym[i], c.ckks_decrypt(zs[i].data, 2.0 ** 68 / P["q"][lvl]))
+        assert re >= 10 and im >= 10
+    # second run on the same task object reuses the cached device context
+    ns2 = t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
+                 Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("out_z_list", zs)])
+    assert ns2 > 0 and np.array_equal(zs[0].data, o.ckks_mult_relin_rescale(lvl, xs[0], ys[0], rlk, lvl))
+    t.close()
+
+
+def test_ckks_cmc_ct3_output_and_wrong_level_error():
+    need_gpu()
+    from lattisense_amd._native import LsaError
+    from lattisense_amd.task import Argument, Ciphertext
+    g, P, o, c = _load("ckks_n4096_cmc")
+    n, lvl = P["n"], 3
+    _, xs = _ckks_inputs(c, n, lvl, N_OP, 3)
+    _, ys = _ckks_inputs(c, n, lvl, N_OP, 4)
+    t = _task("ckks_n4096_cmc")
+    zs = [Ciphertext.empty(2, lvl, n) for _ in range(N_OP)]      # ct3 is a legal task output
+    t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys])],
+          [Argument("out_z_list", zs)])
+    for i in range(N_OP):
+        assert np.array_equal(zs[i].data, o.ckks_mult(lvl, xs[i], ys[i]))
+    bad = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP)]     # wrong degree: the import executor must refuse
+    with pytest.raises(LsaError, match="was allocated at level/degree"):
+        t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys])],
+              [Argument("out_z_list", bad)])
+    wrong_in = [Ciphertext(x[:, :3]) for x in xs]                 # inputs one level too low
+    with pytest.raises(LsaError, match="task expects"):
+        t.run([Argument("in_x_list", wrong_in), Argument("in_y_list", [Ciphertext(y) for y in ys])],
+              [Argument("out_z_list", zs)])
+    t.close()
+
+
+def test_ckks_rotations_task():
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, GaloisKey, KeySwitchKey
+    from oracle.client import galois_element_for_col_rotation, galois_element_for_row_rotation, mean_precision_bits
+    g, P, o, c = _load("ckks_n4096_advanced_rotate_col")
+    n, lvl, steps = P["n"], 3, [1, 2, 5]
+    xm, xs = _ckks_inputs(c, n, lvl, N_OP, 5)
+    elts = {s: galois_element_for_col_rotation(s, n) for s in steps}
+    keys = {e: c.gen_galois_key(e, lvl) for e in elts.values()}
+    glk = GaloisKey({e: KeySwitchKey(k, lvl, len(P["p"])) for e, k in keys.items()})
+    t = _task("ckks_n4096_advanced_rotate_col")
+    ys = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP * len(steps))]
+    t.run([Argument("arg_x", [Ciphertext(x) for x in xs]), Argument("glk_ntt", [glk])], [Argument("arg_y", ys)])
+    assert t.last_run_stats()["gpu_batches"] == len(steps)       # one batched launch per Galois element
+    for i in range(N_OP):
+        for j, s in enumerate(steps):
+            want = o.ckks_rotate(lvl, xs[i], elts[s], keys[elts[s]], lvl)
+            got = ys[i * len(steps) + j].data
+            assert np.array_equal(got, want)
+            re, im = mean_precision_bits(np.roll(xm[i], -s), c.ckks_decrypt(got, 2.0 ** 34))
+            assert re >= 10 and im >= 10
+    t.close()
+    # conjugation (rotate_row)
+    g, P, o, c = _load("ckks_n4096_rotate_row")
+    lvl = 2
+    xm, xs = _ckks_inputs(c, n, lvl, N_OP, 6)
+    e = galois_element_for_row_rotation(n)
+    k = c.gen_galois_key(e, lvl)
+    t = _task("ckks_n4096_rotate_row")
+    ys = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP)]
+    t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]),
+           Argument("glk_ntt", [GaloisKey({e: KeySwitchKey(k, lvl, len(P["p"]))})])], [Argument("out_y_list", ys)])
+    for i in range(N_OP):
+        assert np.array_equal(ys[i].data, o.ckks_rotate(lvl, xs[i], e, k, lvl))
+    t.close()
+
+
+def test_ckks_elementwise_and_plaintext_tasks():
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, Plaintext
+    g, P, o, c = _load("ckks_n4096_add_sub_neg_drop")
+    n, lvl = P["n"], 3
+    _, xs = _ckks_inputs(c, n, lvl, N_OP, 7)
+    _, ys = _ckks_inputs(c, n, lvl, N_OP, 8)
+    t = _task("ckks_n4096_add_sub_neg_drop")
+    ds = [Ciphertext.empty(1, lvl - 1, n) for _ in range(N_OP)]
+    t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys])],
+          [Argument("out_d_list", ds)])
+    for i in range(N_OP):
+        for pl in range(2):
+            for j in range(lvl):     # (x+y) - (-x), then one level dropped
+                s = o.vec("add", j, xs[i][pl, j], ys[i][pl, j])
+                w = o.vec("sub", j, s, o.vec("neg", j, xs[i][pl, j]))
+                assert np.array_equal(ds[i].data[pl, j], w)
+    t.close()
+    g, P, o, c = _load("ckks_n4096_cmp_cap")
+    lvl = 2
+    _, xs = _ckks_inputs(c, n, lvl, N_OP, 9)
+    rng = np.random.default_rng(10)
+    pts = [np.stack([rng.integers(0, P["q"][j], size=n, dtype=np.uint64) for j in range(lvl + 1)]) for _ in range(N_OP)]
+    t = _task("ckks_n4096_cmp_cap")
+    zs = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP)]
+    t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Plaintext(p) for p in pts])],
+          [Argument("out_z_list", zs)])
+    for i in range(N_OP):
+        for j in range(lvl + 1):     # x*pt + pt: both polys multiplied, pt added to c0 only
+            m0 = o.vec("mul", j, xs[i][0, j], pts[i][j])
+            m1 = o.vec("mul", j, xs[i][1, j], pts[i][j])
+            assert np.array_equal(zs[i].data[0, j], o.vec("add", j, m0, pts[i][j]))
+            assert np.array_equal(zs[i].data[1, j], m1)
+    t.close()
+
+
+def test_bfv_tasks():
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, GaloisKey, KeySwitchKey
+    from oracle.client import galois_element_for_col_rotation, galois_element_for_row_rotation
+    g, P, o, c = _load("bfv_n4096_cmc_relin")
+    n, lvl, t_mod = P["n"], 3, P["t"]
+    rng = np.random.default_rng(11)
+    xm = [rng.integers(0, t_mod, size=n, dtype=np.uint64) for _ in range(N_OP)]
+    ym = [rng.integers(0, t_mod, size=n, dtype=np.uint64) for _ in range(N_OP)]
+    xs, ys = [c.bfv_encrypt(m, lvl) for m in xm], [c.bfv_encrypt(m, lvl) for m in ym]
+    rlk = c.gen_relin_key(lvl)
+    t = _task("bfv_n4096_cmc_relin")
+    zs = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP)]
+    t.run([Argument("xs", [Ciphertext(x) for x in xs]), Argument("ys", [Ciphertext(y) for y in ys]),
+           Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("zs", zs)])
+    for i in range(N_OP):
+        assert np.array_equal(zs[i].data, o.bfv_mult_relin(lvl, xs[i], ys[i], rlk, lvl))
+        assert np.array_equal(c.bfv_decrypt(zs[i].data), xm[i] * ym[i] % np.uint64(t_mod))   # test_gpu_bfv.cpp:332-335
+    t.close()
+    # rotate_cols(x, 3) = NAF 4 - 1: two chained rotate_col nodes with two Galois keys
+    g, P, o, c = _load("bfv_n4096_rotate_col3")
+    lvl = 2
+    xm = [(np.arange(n, dtype=np.uint64) * (i + 1)) % np.uint64(t_mod) for i in range(N_OP)]
+    xs = [c.bfv_encrypt(m, lvl) for m in xm]
+    elts = [v["galois_element"] for v in g["data"].values() if v["type"] == "glk"]
+    assert sorted(elts) == sorted([galois_element_for_col_rotation(4, n), galois_element_for_col_rotation(-1, n)])
+    glk = GaloisKey({e: KeySwitchKey(c.gen_galois_key(e, lvl), lvl, len(P["p"])) for e in elts})
+    t = _task("bfv_n4096_rotate_col3")
+    ys = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP)]
+    t.run([Argument("xs", [Ciphertext(x) for x in xs]), Argument("glk_ntt", [glk])], [Argument("ys", ys)])
+    h = n // 2
+    for i in range(N_OP):
+        exp = np.concatenate([np.roll(xm[i][:h], -3), np.roll(xm[i][h:], -3)])
+        assert np.array_equal(c.bfv_decrypt(ys[i].data), exp)                               # test_gpu_bfv.cpp:486
+    t.close()
+    g, P, o, c = _load("bfv_n4096_rotate_row")
+    xs = [c.bfv_encrypt(m, lvl) for m in xm]
+    e = galois_element_for_row_rotation(n)
+    k = c.gen_galois_key(e, lvl)
+    t = _task("bfv_n4096_rotate_row")
+    ys = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP)]
+    t.run([Argument("xs", [Ciphertext(x) for x in xs]), Argument("glk_ntt", [GaloisKey({e: KeySwitchKey(k, lvl, len(P["p"]))})])],
+          [Argument("ys", ys)])
+    for i in range(N_OP):
+        assert np.array_equal(ys[i].data, o.bfv_rotate(lvl, xs[i], e, k, lvl))
+        assert np.array_equal(c.bfv_decrypt(ys[i].data), np.concatenate([xm[i][h:], xm[i][:h]]))  # :551
+    t.close()

@@ -1,0 +1,122 @@
+"""Generates the task-graph fixtures under tests/golden/tasks/ with the reference's Python frontend.
+
+Runs ONLY in the build container (imports /root/reference/frontend, pure Python + networkx); the output is plain
+JSON data (mega_ag.json + task_signature.json per task), committed, and is all that travels to the GPU box.
+Parameter sets are small custom ones (prime chains from the reference's own defaults, truncated) so the oracle can
+check whole task runs in seconds; graph shapes are the reference's test/benchmark shapes:
+  unittests/test_gpu_ckks.py:287-317 (cmc_relin, cmc_relin_rescale), :396-445 (rotate_col / rotate_row),
+  unittests/test_gpu_bfv.py (cmc_relin, rotate), examples/benchmark_gpu/benchmark_gpu.py:25-75 (n_op disjoint subgraphs).
+"""
+import os
+import shutil
+import sys
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from frontend.custom_task import *  # noqa: E402,F401,F403
+from lattisense_amd import params as P  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "tasks")
+N_OP = 4
+
+
+def emit(name, inputs, outputs):
+    d = os.path.join(OUT, name)
+    if os.path.exists(d):
+        shutil.rmtree(d)
+    os.makedirs(d)
+    process_custom_task(input_args=inputs, offline_input_args=[], output_args=outputs, output_instruction_path=d,
+                        fpga_acc=False)
+    # keep only the two files the runtime reads
+    for f in os.listdir(d):
+        if f not in ("mega_ag.json", "task_signature.json"):
+            p = os.path.join(d, f)
+            shutil.rmtree(p) if os.path.isdir(p) else os.remove(p)
+
+
+def ckks_param(n, nq):
+    D = P.CKKS_DEFAULT[16384]
+    return CkksParam.create_custom_param(n=n, q=D["q"][:nq], p=D["p"], scale=float(2 ** 34))
+
+
+def bfv_param(n, nq):
+    D = P.BFV_DEFAULT[16384]
+    return BfvParam.create_custom_param(n=n, q=D["q"][:nq], p=D["p"], t=D["t"])
+
+
+def main():
+    # ---- CKKS N=4096, 5 primes
+    set_fhe_param(ckks_param(4096, 5))
+    lv = 4
+    xs = [CkksCiphertextNode(f"x_{i}", level=lv) for i in range(N_OP)]
+    ys = [CkksCiphertextNode(f"y_{i}", level=lv) for i in range(N_OP)]
+    zs = [rescale(mult_relin(xs[i], ys[i]), f"z_{i}") for i in range(N_OP)]
+    emit("ckks_n4096_cmc_relin_rescale", [Argument("in_x_list", xs), Argument("in_y_list", ys)],
+         [Argument("out_z_list", zs)])
+
+    set_fhe_param(ckks_param(4096, 5))
+    xs = [CkksCiphertextNode(f"x_{i}", level=3) for i in range(N_OP)]
+    ys = [CkksCiphertextNode(f"y_{i}", level=3) for i in range(N_OP)]
+    zs = [mult(xs[i], ys[i], f"z_{i}") for i in range(N_OP)]
+    emit("ckks_n4096_cmc", [Argument("in_x_list", xs), Argument("in_y_list", ys)], [Argument("out_z_list", zs)])
+
+    set_fhe_param(ckks_param(4096, 5))
+    xs = [CkksCiphertextNode(f"x_{i}", level=3) for i in range(N_OP)]
+    steps = [1, 2, 5]
+    ys = [advanced_rotate_cols(xs[i], steps, [f"y_{i}_{s}" for s in steps]) for i in range(N_OP)]
+    emit("ckks_n4096_advanced_rotate_col", [Argument("arg_x", xs)], [Argument("arg_y", ys)])
+
+    set_fhe_param(ckks_param(4096, 5))
+    xs = [CkksCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
+    ys = [rotate_rows(xs[i], f"y_{i}") for i in range(N_OP)]
+    emit("ckks_n4096_rotate_row", [Argument("in_x_list", xs)], [Argument("out_y_list", ys)])
+
+    set_fhe_param(ckks_param(4096, 5))
+    xs = [CkksCiphertextNode(f"x_{i}", level=3) for i in range(N_OP)]
+    ys = [CkksCiphertextNode(f"y_{i}", level=3) for i in range(N_OP)]
+    ws = [sub(add(xs[i], ys[i]), neg(xs[i]), f"w_{i}") for i in range(N_OP)]      # (x+y) - (-x)
+    ds = [drop_level(ws[i], 1, f"d_{i}") for i in range(N_OP)]
+    emit("ckks_n4096_add_sub_neg_drop", [Argument("in_x_list", xs), Argument("in_y_list", ys)],
+         [Argument("out_d_list", ds)])
+
+    # a graph this backend must REJECT at bind time (ring-t plaintext operand, scheduled for a later round)
+    set_fhe_param(ckks_param(4096, 5))
+    xs = [CkksCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
+    ys = [CkksPlaintextRingtNode(f"y_{i}") for i in range(N_OP)]
+    zs = [add(xs[i], ys[i], f"z_{i}") for i in range(N_OP)]
+    emit("ckks_n4096_cap_ringt_unsupported", [Argument("in_x_list", xs), Argument("in_y_list", ys)],
+         [Argument("out_z_list", zs)])
+
+    # CKKS ct+pt, ct*pt with full (NTT-domain) plaintexts
+    set_fhe_param(ckks_param(4096, 5))
+    xs = [CkksCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
+    ys = [CkksPlaintextNode(f"y_{i}", level=2) for i in range(N_OP)]
+    zs = [add(mult(xs[i], ys[i]), ys[i], f"z_{i}") for i in range(N_OP)]
+    emit("ckks_n4096_cmp_cap", [Argument("in_x_list", xs), Argument("in_y_list", ys)], [Argument("out_z_list", zs)])
+
+    # ---- BFV N=4096, 4 primes
+    set_fhe_param(bfv_param(4096, 4))
+    lv = 3
+    xs = [BfvCiphertextNode(f"x_{i}", level=lv) for i in range(N_OP)]
+    ys = [BfvCiphertextNode(f"y_{i}", level=lv) for i in range(N_OP)]
+    zs = [mult_relin(xs[i], ys[i], f"z_{i}") for i in range(N_OP)]
+    emit("bfv_n4096_cmc_relin", [Argument("xs", xs), Argument("ys", ys)], [Argument("zs", zs)])
+
+    set_fhe_param(bfv_param(4096, 4))
+    xs = [BfvCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
+    ys = [rotate_cols(xs[i], 3, f"y_{i}") for i in range(N_OP)]     # NAF decomposition: 3 = 4 - 1 -> two rotate_col nodes
+    emit("bfv_n4096_rotate_col3", [Argument("xs", xs)], [Argument("ys", ys)])
+
+    set_fhe_param(bfv_param(4096, 4))
+    xs = [BfvCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
+    ys = [rotate_rows(xs[i], f"y_{i}") for i in range(N_OP)]
+    emit("bfv_n4096_rotate_row", [Argument("xs", xs)], [Argument("ys", ys)])
+
+
+if __name__ == "__main__":
+    main()
+    for d in sorted(os.listdir(OUT)):
+        print(d, os.listdir(os.path.join(OUT, d)))
