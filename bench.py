@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep"])
+    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep", "task_ckks", "task_bfv"])
     ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU (0 = workload default)")
     ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
     ap.add_argument("--ntt-chunk-mib", type=int, default=-1, help="Infinity-Cache chunk of two-pass NTTs (-1 = default)")
@@ -72,8 +72,55 @@ def workload_config(name):
                 label="BFV N=2^14 4 primes batch 1024 ct NTT+INTT", unit="GB/s", metric="ntt_intt_algorithmic_bandwidth")
 
 
+def run_task_workload(args):
+    """End-to-end through the drop-in boundary run_fhe_gpu_task with HOST buffers (export, pinned staging, H2D, batched
+    operators, D2H, import): the PCIe-inclusive rate noted in DESIGN.md §6 — never the headline `value`."""
+    import numpy as np
+    from lattisense_amd.task import Argument, Ciphertext, FheTaskGpu, KeySwitchKey
+    name = "ckks_n65536_l12_cmc_relin_rescale_x64" if args.workload == "task_ckks" else "bfv_n16384_l3_cmc_relin_x256"
+    path = os.path.join(ROOT, "tests", "golden", "tasks_bench", name)
+    g = json.load(open(os.path.join(path, "mega_ag.json")))
+    P = g["parameter"]
+    n, q, p = P["n"], P["q"][: P["max_level"] + 1], P["p"]
+    n_op = len(g["outputs"])
+    lvl = 12 if args.workload == "task_ckks" else 3
+    out_lvl = lvl - 1 if args.workload == "task_ckks" else lvl
+    rng = np.random.default_rng(0)
+
+    def rand(shape_prefix, mods):
+        out = np.empty((*shape_prefix, len(mods), n), dtype=np.uint64)
+        for i, m in enumerate(mods):
+            out[..., i, :] = rng.integers(0, m, size=(*shape_prefix, n), dtype=np.uint64)
+        return out
+
+    xs = [Ciphertext(rand((2,), q[: lvl + 1])) for _ in range(n_op)]
+    ys = [Ciphertext(rand((2,), q[: lvl + 1])) for _ in range(n_op)]
+    zs = [Ciphertext.empty(1, out_lvl, n) for _ in range(n_op)]
+    beta = (lvl + 1 + len(p) - 1) // len(p)
+    rlk = KeySwitchKey(rand((beta, 2), q[: lvl + 1] + p), lvl, len(p))
+    t = FheTaskGpu(path)
+    ins = [Argument("xs", xs), Argument("ys", ys), Argument("rlk_ntt", [rlk])]
+    outs = [Argument("zs", zs)]
+    for _ in range(args.warmup):
+        t.run(ins, outs)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t.run(ins, outs)
+    dt = time.perf_counter() - t0
+    st = t.last_run_stats()
+    print(json.dumps({
+        "metric": "task_end_to_end_throughput", "value": n_op * args.steps / dt, "unit": "ciphertexts/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": name + " through run_fhe_gpu_task (host buffers, PCIe-inclusive)", "n_op": n_op,
+                   "gpu_nodes": st["gpu_nodes"], "batched_launch_groups": st["gpu_batches"]},
+        "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload.startswith("task_"):
+        return run_task_workload(args)
     import torch
     import torch.distributed as dist
 
@@ -84,9 +131,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from lattisense_amd import sharding
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        sharding.init_process_group("nccl", rank, world, device=dev)   # backend "nccl" is RCCL on ROCm
 
     from lattisense_amd._native import check, lib
     from lattisense_amd.device import DeviceContext
@@ -131,8 +179,7 @@ def main():
             key_t = uniform((beta, 2), kmods)
         else:
             key_t = torch.empty(beta, 2, len(kmods), n, dtype=torch.int64, device=dev)
-        if world > 1:
-            dist.broadcast(key_t, src=0)
+        sharding.broadcast_key(key_t, src=0)
         torch.cuda.synchronize()
         assert key_t.numel() * 8 == ctx.key_bytes(lvl)
         key = ctx.adopt_key(key_t.data_ptr(), lvl)
@@ -160,8 +207,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        sharding.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -174,10 +220,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     check(L_.lsa_profile_end(ctx.h))
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = sharding.max_over_ranks(dt, device=dev)
 
     ms_per_step = dt / args.steps * 1e3
     if args.workload == "ntt":

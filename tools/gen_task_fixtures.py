@@ -116,7 +116,29 @@ def main():
     emit("bfv_n4096_rotate_row", [Argument("xs", xs)], [Argument("ys", ys)])
 
 
+def bench_fixtures():
+    """Benchmark-shaped graphs (examples/benchmark_gpu/benchmark_gpu.py:25-58: n_op disjoint mult_relin subgraphs),
+    CKKS at the BASELINE N=2^16 / level-12 shape with the rescale the headline metric includes."""
+    global OUT
+    OUT = os.path.join(ROOT, "tests", "golden", "tasks_bench")
+    D = P.CKKS_DEFAULT[65536]
+    set_fhe_param(CkksParam.create_custom_param(n=65536, q=D["q"][:13], p=D["p"], scale=float(2 ** 45)))
+    n_op, lv = 64, 12
+    xs = [CkksCiphertextNode(f"x_{i}", level=lv) for i in range(n_op)]
+    ys = [CkksCiphertextNode(f"y_{i}", level=lv) for i in range(n_op)]
+    zs = [rescale(mult_relin(xs[i], ys[i]), f"z_{i}") for i in range(n_op)]
+    emit("ckks_n65536_l12_cmc_relin_rescale_x64", [Argument("xs", xs), Argument("ys", ys)], [Argument("zs", zs)])
+    B = P.BFV_DEFAULT[16384]
+    set_fhe_param(BfvParam.create_custom_param(n=16384, q=B["q"], p=B["p"], t=B["t"]))
+    n_op, lv = 256, 3
+    xs = [BfvCiphertextNode(f"x_{i}", level=lv) for i in range(n_op)]
+    ys = [BfvCiphertextNode(f"y_{i}", level=lv) for i in range(n_op)]
+    zs = [mult_relin(xs[i], ys[i], f"z_{i}") for i in range(n_op)]
+    emit("bfv_n16384_l3_cmc_relin_x256", [Argument("xs", xs), Argument("ys", ys)], [Argument("zs", zs)])
+
+
 if __name__ == "__main__":
     main()
+    bench_fixtures()
     for d in sorted(os.listdir(OUT)):
         print(d, os.listdir(os.path.join(OUT, d)))
