@@ -73,6 +73,7 @@ SIGNATURES = {
     "lsa_bfv_mult_relin": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_ll, c_ll, c_vp]),
     "lsa_set_tile_batch": (c_int, [c_vp, c_int]),
     "lsa_set_fp64_ntt": (c_int, [c_vp, c_int]),
+    "lsa_set_dual_stream": (c_int, [c_vp, c_int]),
     "lsa_set_ntt_chunk_mib": (c_int, [c_vp, c_int]),
     "lsa_profile_begin": (c_int, [c_vp, c_int]),
     "lsa_profile_end": (c_int, [c_vp]),

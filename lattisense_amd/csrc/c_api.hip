@@ -332,6 +332,9 @@ int lsa_profile_read(lsa_context ctx, int kind, double* total_ms, double* total_
     });
 }
 
+int lsa_set_dual_stream(lsa_context ctx, int enable) {
+    return guard([&] { C(ctx).dual_stream = enable ? 1 : 0; });
+}
 int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib) {
     return guard([&] {
         LSA_REQUIRE(mib >= 0, "chunk size must be >= 0");

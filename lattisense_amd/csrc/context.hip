@@ -64,6 +64,11 @@ Context::~Context() {
     (void)hipFree(d_scale_d);
     (void)hipFree(ws);
     (void)hipFree(ws2);
+    if (aux_stream) {
+        (void)hipStreamDestroy(aux_stream);
+        (void)hipEventDestroy(ev_fork);
+        (void)hipEventDestroy(ev_join);
+    }
     for (auto& sm : prof_samples) {
         (void)hipEventDestroy(sm.e0);
         (void)hipEventDestroy(sm.e1);
@@ -86,6 +91,21 @@ u64* Context::workspace(size_t words, hipStream_t s) {
         ws_words = words;
     }
     return ws;
+}
+
+void Context::fork_aux(hipStream_t s) {
+    if (!aux_stream) {
+        LSA_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+        LSA_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        LSA_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    LSA_HIP(hipEventRecord(ev_fork, s));
+    LSA_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+}
+
+void Context::join_aux(hipStream_t s) {
+    LSA_HIP(hipEventRecord(ev_join, aux_stream));
+    LSA_HIP(hipStreamWaitEvent(s, ev_join, 0));
 }
 
 u64* Context::workspace2(size_t words, hipStream_t s) {

@@ -10,13 +10,11 @@ static constexpr int TPB = 256;
 #ifndef LSA_NTT_WAVES
 #define LSA_NTT_WAVES 3   // min waves/SIMD the register allocator must allow (= co-resident 256-thread workgroups per CU)
 #endif
-__global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
-    if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
-    const int tid = threadIdx.x;
-    ntt_phase_load(a, bc, tid, lds);
-    __syncthreads();
+#ifndef LSA_NTT_TILES_PER_WG
+#define LSA_NTT_TILES_PER_WG 1   // >1: a workgroup walks this many consecutive tiles, prefetching tile k+1 during tile k
+#endif
+
+__device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     const int np = (a.mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO, base = a.mu / np, extra = a.mu % np;
     if (!a.inverse) {
         int sig = 0;
@@ -35,7 +33,49 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(Ntt
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+#if LSA_NTT_TILES_PER_WG == 1
+    const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
+    if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
+    ntt_phase_load(a, bc, tid, lds);
+    __syncthreads();
+#if defined(LSA_NTT_DIAG_COPY_ONLY)   // diagnostic build: data movement of the pass structure without butterflies
     ntt_phase_store(a, bc, tid, lds);
+    return;
+#endif
+    ntt_butterfly_phases(a, bc, tid, lds);
+    ntt_phase_store(a, bc, tid, lds);
+#else
+    // software-pipelined walk over consecutive tiles (same limb and tile index, different batch items: same twiddles)
+    const long long first = (long long)blockIdx.x * LSA_NTT_TILES_PER_WG;
+    u64 stage[2 * LSA_NTT_STAGE_PAIRS];
+    NttBlockCtx nxt = ntt_decode_block(a, first < a.total_tiles ? first : 0);
+    bool have_nxt = first < a.total_tiles && nxt.mod != LSA_ROW_SKIP;
+    if (have_nxt) ntt_phase_fetch(a, nxt, tid, stage);
+    for (int k = 0; k < LSA_NTT_TILES_PER_WG; k++) {
+        const long long bid = first + k;
+        if (bid >= a.total_tiles) break;
+        const NttBlockCtx bc = nxt;
+        const bool have = have_nxt;
+        have_nxt = false;
+        if (k + 1 < LSA_NTT_TILES_PER_WG && bid + 1 < a.total_tiles) {
+            nxt = ntt_decode_block(a, bid + 1);
+            have_nxt = nxt.mod != LSA_ROW_SKIP;
+        }
+        if (have) ntt_phase_commit(a, bc, tid, lds, stage);
+        __syncthreads();
+        if (have_nxt) ntt_phase_fetch(a, nxt, tid, stage);   // in flight during the butterflies below
+        if (have) {
+            ntt_butterfly_phases(a, bc, tid, lds);
+            ntt_phase_store(a, bc, tid, lds);
+        }
+        __syncthreads();   // LDS is reused by the next tile
+    }
+#endif
 }
 
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch_stride, int rows, const RowMap& rm,
@@ -80,8 +120,10 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
             a.src_stride = step == 0 ? src_stride : dst_stride;
             a.dst = dst + (long long)b0 * dst_stride;
             a.dst_stride = dst_stride;
-            const long long nblocks = (long long)nb * rows * (1 << (a.logn - a.tau));
+            a.total_tiles = (long long)nb * rows * (1 << (a.logn - a.tau));
+            const long long nblocks = (a.total_tiles + LSA_NTT_TILES_PER_WG - 1) / LSA_NTT_TILES_PER_WG;
             LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
+            LSA_REQUIRE((1 << a.tau) <= 2 * LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS, "ntt: tile larger than the staging registers");
             const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
             // one launch = one pass = 1/npass of the limb transforms it touches (algorithmic 16*N bytes per transform)
             ProfScope ps(c, PROF_NTT, 16.0 * c.n * active_rows * nb / c.plan.npass, s);
@@ -248,6 +290,8 @@ struct BaseConvArgs {
     BaseConvRows rows;
 };
 
+// NSMAX = compile-time bound of the source-limb loops (registers for y[] scale with it; dispatched from ns)
+template <int NSMAX>
 __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
     const BaseConvConsts& K = *g.k;
     const int x = (blockIdx.x * TPB + threadIdx.x) * 2;
@@ -255,10 +299,10 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
     const u64* src = g.src + b * g.ssrc + x;
     u64* dst = g.dst + b * g.sdst + x;
     const int ns = K.ns, nd = K.nd;
-    u64 y[LSA_BC_MAX_SRC][2];
+    u64 y[NSMAX][2];
     double vf0 = 0.0, vf1 = 0.0;
 #pragma unroll
-    for (int i = 0; i < LSA_BC_MAX_SRC; i++) {
+    for (int i = 0; i < NSMAX; i++) {
         if (i < ns) {
             const ModDev m = g.mods[K.src_mod[i]];
             ulonglong2 v = ld2(src + ((long long)g.rows.src_row[i] << g.logn));
@@ -281,7 +325,7 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
         const ModDev m = g.mods[K.dst_mod[j]];
         u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0, r0 = 0, r1 = 0;
 #pragma unroll
-        for (int i = 0; i < LSA_BC_MAX_SRC; i++) {
+        for (int i = 0; i < NSMAX; i++) {
             if (i < ns) {
                 const u64 w = K.shat_m[j][i];
                 mac128(h0, l0, y[i][0], w);
@@ -319,7 +363,16 @@ void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows
     g.rows = rows;
     ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns + k->nd), s);
     const unsigned gz = (unsigned)((k->nd + LSA_BC_TGT_PER_BLOCK - 1) / LSA_BC_TGT_PER_BLOCK);
-    hipLaunchKernelGGL(k_baseconv, dim3((unsigned)(c.n / (2 * TPB)), (unsigned)batch, gz), dim3(TPB), 0, s, g);
+    const dim3 grid((unsigned)(c.n / (2 * TPB)), (unsigned)batch, gz);
+    const int ns = k->ns;
+    if (ns <= 1) hipLaunchKernelGGL(k_baseconv<1>, grid, dim3(TPB), 0, s, g);
+    else if (ns <= 2) hipLaunchKernelGGL(k_baseconv<2>, grid, dim3(TPB), 0, s, g);
+    else if (ns <= 3) hipLaunchKernelGGL(k_baseconv<3>, grid, dim3(TPB), 0, s, g);
+    else if (ns <= 4) hipLaunchKernelGGL(k_baseconv<4>, grid, dim3(TPB), 0, s, g);
+    else if (ns <= 5) hipLaunchKernelGGL(k_baseconv<5>, grid, dim3(TPB), 0, s, g);
+    else if (ns <= 8) hipLaunchKernelGGL(k_baseconv<8>, grid, dim3(TPB), 0, s, g);
+    else if (ns <= 12) hipLaunchKernelGGL(k_baseconv<12>, grid, dim3(TPB), 0, s, g);
+    else hipLaunchKernelGGL(k_baseconv<LSA_BC_MAX_SRC>, grid, dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
 
@@ -331,10 +384,14 @@ struct KsMacArgs {
     u64* acc;
     long long scx, sext, sacc;
     const ModDev* mods;
-    int logn, L, np, nq, beta, kcomp, klvl;
+    int logn, L, np, nq, beta, kcomp, klvl, batch, bpt;
 };
 
-// grid: x = T * (N/2/TPB), y = batch.  key is in Montgomery form, so sum_d ext_d*key_d needs ONE REDC per output.
+// grid: x = T * (N/2/TPB), y = groups of `bpt` batch items.  The key is in Montgomery form, so sum_d ext_d*key_d needs
+// ONE REDC per output.  A thread keeps its 2*beta key words in registers and walks `bpt` ciphertexts with them: the key
+// (68 MiB at the headline shape) is then streamed once per group instead of once per ciphertext.
+// KB = number of digits whose key words are register-resident (0: stream the key per ciphertext)
+template <int KB>
 __global__ __launch_bounds__(TPB) void k_ks_mac(KsMacArgs g) {
     const int chunks = (1 << g.logn) / (2 * TPB);
     const int tl = blockIdx.x / chunks;
@@ -343,35 +400,64 @@ __global__ __launch_bounds__(TPB) void k_ks_mac(KsMacArgs g) {
     const int mi = tl < g.L ? tl : g.nq + (tl - g.L);
     const int kj = tl < g.L ? tl : g.klvl + 1 + (tl - g.L);
     const ModDev m = g.mods[mi];
-    const long long b = blockIdx.y;
     const long long N = 1LL << g.logn;
-    u64 h00 = 0, l00 = 0, h01 = 0, l01 = 0, h10 = 0, l10 = 0, h11 = 0, l11 = 0;
-    u64 r00 = 0, r01 = 0, r10 = 0, r11 = 0;
-    for (int d = 0; d < g.beta; d++) {
-        const bool own = tl < g.L && tl >= d * g.np && tl < (d + 1) * g.np;
-        const u64* pe = own ? g.cx + b * g.scx + tl * N + x : g.ext + b * g.sext + ((long long)d * T + tl) * N + x;
-        const ulonglong2 e = ld2(pe);
-        const u64* pk = g.key + ((long long)(d * 2) * g.kcomp + kj) * N + x;
-        const ulonglong2 k0 = ld2(pk), k1 = ld2(pk + (long long)g.kcomp * N);
-        mac128(h00, l00, e.x, k0.x);
-        mac128(h01, l01, e.y, k0.y);
-        mac128(h10, l10, e.x, k1.x);
-        mac128(h11, l11, e.y, k1.y);
-        if ((d & 7) == 7) {  // fold so the 128-bit sum stays below q*2^64 (8 products of < q^2, q < 2^61)
-            r00 = add_mod(r00, csub(mont_redc_lazy(h00, l00, m.q, m.qinv), m.q), m.q);
-            r01 = add_mod(r01, csub(mont_redc_lazy(h01, l01, m.q, m.qinv), m.q), m.q);
-            r10 = add_mod(r10, csub(mont_redc_lazy(h10, l10, m.q, m.qinv), m.q), m.q);
-            r11 = add_mod(r11, csub(mont_redc_lazy(h11, l11, m.q, m.qinv), m.q), m.q);
-            h00 = l00 = h01 = l01 = h10 = l10 = h11 = l11 = 0;
+    const int own_d = tl < g.L ? tl / g.np : -1;   // the digit that contains this limb reads cx directly
+    ulonglong2 k0[KB > 0 ? KB : 1], k1[KB > 0 ? KB : 1];
+    constexpr bool in_regs = KB > 0;
+    if constexpr (in_regs) {
+#pragma unroll
+        for (int d = 0; d < KB; d++) {
+            if (d < g.beta) {
+                const u64* pk = g.key + ((long long)(d * 2) * g.kcomp + kj) * N + x;
+                k0[d] = ld2(pk);
+                k1[d] = ld2(pk + (long long)g.kcomp * N);
+            }
         }
     }
-    r00 = add_mod(r00, csub(mont_redc_lazy(h00, l00, m.q, m.qinv), m.q), m.q);
-    r01 = add_mod(r01, csub(mont_redc_lazy(h01, l01, m.q, m.qinv), m.q), m.q);
-    r10 = add_mod(r10, csub(mont_redc_lazy(h10, l10, m.q, m.qinv), m.q), m.q);
-    r11 = add_mod(r11, csub(mont_redc_lazy(h11, l11, m.q, m.qinv), m.q), m.q);
-    u64* pa = g.acc + b * g.sacc + tl * N + x;
-    st2(pa, r00, r01);
-    st2(pa + (long long)T * N, r10, r11);
+    const int b_begin = blockIdx.y * g.bpt;
+    const int b_end = min(g.batch, b_begin + g.bpt);
+    for (long long b = b_begin; b < b_end; b++) {
+        u64 h00 = 0, l00 = 0, h01 = 0, l01 = 0, h10 = 0, l10 = 0, h11 = 0, l11 = 0;
+        u64 r00 = 0, r01 = 0, r10 = 0, r11 = 0;
+        if constexpr (in_regs) {
+#pragma unroll
+            for (int d = 0; d < KB; d++) {
+                if (d < g.beta) {
+                    const u64* pe = d == own_d ? g.cx + b * g.scx + tl * N + x : g.ext + b * g.sext + ((long long)d * T + tl) * N + x;
+                    const ulonglong2 e = ld2(pe);
+                    mac128(h00, l00, e.x, k0[d].x);
+                    mac128(h01, l01, e.y, k0[d].y);
+                    mac128(h10, l10, e.x, k1[d].x);
+                    mac128(h11, l11, e.y, k1[d].y);
+                }
+            }
+        } else {
+            for (int d = 0; d < g.beta; d++) {
+                const u64* pe = d == own_d ? g.cx + b * g.scx + tl * N + x : g.ext + b * g.sext + ((long long)d * T + tl) * N + x;
+                const ulonglong2 e = ld2(pe);
+                const u64* pk = g.key + ((long long)(d * 2) * g.kcomp + kj) * N + x;
+                const ulonglong2 kk0 = ld2(pk), kk1 = ld2(pk + (long long)g.kcomp * N);
+                mac128(h00, l00, e.x, kk0.x);
+                mac128(h01, l01, e.y, kk0.y);
+                mac128(h10, l10, e.x, kk1.x);
+                mac128(h11, l11, e.y, kk1.y);
+                if ((d & 7) == 7) {  // fold so the 128-bit sum stays below q*2^64 (8 products of < q^2, q < 2^61)
+                    r00 = add_mod(r00, csub(mont_redc_lazy(h00, l00, m.q, m.qinv), m.q), m.q);
+                    r01 = add_mod(r01, csub(mont_redc_lazy(h01, l01, m.q, m.qinv), m.q), m.q);
+                    r10 = add_mod(r10, csub(mont_redc_lazy(h10, l10, m.q, m.qinv), m.q), m.q);
+                    r11 = add_mod(r11, csub(mont_redc_lazy(h11, l11, m.q, m.qinv), m.q), m.q);
+                    h00 = l00 = h01 = l01 = h10 = l10 = h11 = l11 = 0;
+                }
+            }
+        }
+        r00 = add_mod(r00, csub(mont_redc_lazy(h00, l00, m.q, m.qinv), m.q), m.q);
+        r01 = add_mod(r01, csub(mont_redc_lazy(h01, l01, m.q, m.qinv), m.q), m.q);
+        r10 = add_mod(r10, csub(mont_redc_lazy(h10, l10, m.q, m.qinv), m.q), m.q);
+        r11 = add_mod(r11, csub(mont_redc_lazy(h11, l11, m.q, m.qinv), m.q), m.q);
+        u64* pa = g.acc + b * g.sacc + tl * N + x;
+        st2(pa, r00, r01);
+        st2(pa + (long long)T * N, r10, r11);
+    }
 }
 
 void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext, const Key& key,
@@ -396,7 +482,15 @@ void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u6
     LSA_REQUIRE(key.level >= level, "key-switch key exported at a lower level than the ciphertext");
     const double T = g.L + c.np;
     ProfScope ps(c, PROF_KSMAC, 8.0 * c.n * (batch * (g.beta * T + 2 * T) + 2.0 * g.beta * T), s);
-    hipLaunchKernelGGL(k_ks_mac, ew_grid(c, g.L + c.np, batch), dim3(TPB), 0, s, g);
+    // enough workgroups to fill the chip, as few key re-reads as possible
+    const dim3 grid1 = ew_grid(c, g.L + c.np, 1);
+    const int groups = std::max(1, std::min(batch, (int)((2048 + grid1.x - 1) / grid1.x)));
+    g.batch = batch;
+    g.bpt = (batch + groups - 1) / groups;
+    const dim3 grid(grid1.x, (unsigned)((batch + g.bpt - 1) / g.bpt));
+    if (g.beta <= 4) hipLaunchKernelGGL(k_ks_mac<4>, grid, dim3(TPB), 0, s, g);
+    else if (g.beta <= 8) hipLaunchKernelGGL(k_ks_mac<8>, grid, dim3(TPB), 0, s, g);
+    else hipLaunchKernelGGL(k_ks_mac<0>, grid, dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
 

@@ -79,6 +79,11 @@ struct Context {
     double* d_scale_d = nullptr;
     int fp64_ntt = 1;               // use the FP64 butterfly engine for limbs with q < 2^47
     int tile_batch = 0;
+    int dual_stream = 1;            // overlap alternate tiles of an operator on an auxiliary stream
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void fork_aux(hipStream_t s);   // aux stream waits for everything enqueued on s so far
+    void join_aux(hipStream_t s);   // s waits for everything enqueued on the aux stream
     int ntt_chunk_mib = 0;          // >0: two-pass NTTs run pass A+B per chunk of this many MiB (Infinity-Cache reuse)
 
     // sampled HIP-event timing of kernel launches (bench.py roofline leg); off unless lsa_profile_begin was called

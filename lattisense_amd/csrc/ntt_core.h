@@ -29,7 +29,9 @@
 #pragma once
 #include "modarith.h"
 
+#ifndef LSA_NTT_THREADS
 #define LSA_NTT_THREADS 256
+#endif
 #define LSA_MAX_PERIOD 192
 #define LSA_ROW_SKIP 0xFF
 #define LSA_FP64_MAX_BITS 47
@@ -43,6 +45,7 @@ struct NttPassArgs {
     long long src_stride;    // elements between consecutive batch items of src
     long long dst_stride;    // ... of dst
     int batch;            // number of batch items
+    long long total_tiles;   // batch * rows * tiles-per-limb
     int rows;             // limb-polynomials per batch item, each N contiguous elements
     const ModDev* mods;   // [nmod]
     const u64* tw;        // [nmod][N] Montgomery-form psi^{brv(x)} (forward) or psi^{-brv(x)} (inverse)
@@ -154,6 +157,45 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
         }
         lds[lds_addr(l)] = v0;
         lds[lds_addr(l + 1)] = v1;
+    }
+}
+
+// The load phase split in two for software pipelining (async-STAGE split): `fetch` only ISSUES the tile's global loads
+// into registers (they stay in flight while the previous tile's butterflies run), `commit` writes them to LDS later.
+#define LSA_NTT_STAGE_PAIRS 8   // 16-byte pairs per thread: supports tiles up to 2 * 8 * LSA_NTT_THREADS points
+LSA_HD void ntt_phase_fetch(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* stage /*[2*PAIRS]*/) {
+    const u64* g = a.src + bc.base_src;
+    const int half = 1 << (a.tau - 1);
+#pragma unroll
+    for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
+        const int i = tid + p * LSA_NTT_THREADS;
+        if (i < half) {
+            const int x = ntt_global_index(a, bc.tile, 2 * i);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g + x);
+            stage[2 * p] = v.x;
+            stage[2 * p + 1] = v.y;
+#else
+            stage[2 * p] = g[x];
+            stage[2 * p + 1] = g[x + 1];
+#endif
+        }
+    }
+}
+LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, const u64* stage) {
+    const int half = 1 << (a.tau - 1);
+#pragma unroll
+    for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
+        const int i = tid + p * LSA_NTT_THREADS;
+        if (i < half) {
+            u64 v0 = stage[2 * p], v1 = stage[2 * p + 1];
+            if (bc.fp) {
+                v0 = d_to_bits((double)v0);
+                v1 = d_to_bits((double)v1);
+            }
+            lds[lds_addr(2 * i)] = v0;
+            lds[lds_addr(2 * i + 1)] = v1;
+        }
     }
 }
 
@@ -276,7 +318,11 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
+#if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)   // diagnostic build: constant twiddle (wrong results, same arithmetic)
+                        const double T = fp_modmul(v[e + half], (double)(G + j + 3), q, qinv);
+#else
                         const double T = fp_modmul(v[e + half], twj[e >> (RHO - j)], q, qinv);
+#endif
                         const double U = v[e];
                         v[e] = U + T;          // |.| grows by < 1.1q per stage: <= 10.9q < 2^51 over a 9-stage pass
                         v[e + half] = U - T;

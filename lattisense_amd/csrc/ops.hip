@@ -146,6 +146,26 @@ static int pick_tile(const Context& c, size_t rows_per_ct, int batch) {
     return (int)std::min<size_t>(tb, (size_t)batch);
 }
 
+// Runs fn(nb, b0, ws, tb, stream) for every tile of `tb` ciphertexts.  Tiles alternate between the caller's stream and
+// the context's auxiliary stream (each with its own workspace half): every kernel of the pipeline uses only part of the
+// chip's VALU / HBM / latency budget, so two independent tiles in flight fill each other's gaps.
+template <typename F>
+static void for_tiles(Context& c, size_t rows_per_ct, int batch, hipStream_t s, F&& fn) {
+    if (batch <= 0) return;
+    const int tb = pick_tile(c, rows_per_ct, batch);
+    const int ntiles = ceil_div(batch, tb);
+    const bool dual = c.dual_stream && ntiles >= 2;
+    const size_t words = rows_per_ct * (size_t)c.n * tb;
+    u64* ws = c.workspace(words * (dual ? 2 : 1), s);
+    if (dual) c.fork_aux(s);
+    for (int t = 0; t < ntiles; t++) {
+        const int b0 = t * tb, nb = std::min(tb, batch - b0);
+        const bool on_aux = dual && (t & 1);
+        fn(nb, b0, ws + (on_aux ? words : 0), tb, on_aux ? c.aux_stream : s);
+    }
+    if (dual) c.join_aux(s);
+}
+
 // ================================================================================================ CKKS
 void ckks_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int batch, long long sa, long long sb,
                long long sd, hipStream_t s) {
@@ -157,25 +177,17 @@ void ckks_relin(Context& c, int level, const u64* d3, const Key& rlk, u64* out, 
                 hipStream_t s) {
     const long long N = c.n;
     const int L = level + 1;
-    const size_t rows = ks_ws_rows(c, level);
-    const int tb = pick_tile(c, rows, batch);
-    u64* ws = c.workspace(rows * N * tb, s);
-    for (int b0 = 0; b0 < batch; b0 += tb) {
-        const int nb = std::min(tb, batch - b0);
+    for_tiles(c, ks_ws_rows(c, level), batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
         const u64* d = d3 + (size_t)b0 * sd;
-        key_switch(c, level, d + 2LL * L * N, sd, rlk, out + (size_t)b0 * so, so, d, sd, L, 2, nb, ws, s);
-    }
+        key_switch(c, level, d + 2LL * L * N, sd, rlk, out + (size_t)b0 * so, so, d, sd, L, 2, nb, ws, st);
+    });
 }
 
 void ckks_rescale(Context& c, int level, int polys, const u64* in, u64* out, int batch, long long sin, long long sout,
                   hipStream_t s) {
-    const size_t rows = rescale_ws_rows(level, polys);
-    const int tb = pick_tile(c, rows, batch);
-    u64* ws = c.workspace(rows * c.n * tb, s);
-    for (int b0 = 0; b0 < batch; b0 += tb) {
-        const int nb = std::min(tb, batch - b0);
-        rescale(c, level, polys, in + (size_t)b0 * sin, sin, out + (size_t)b0 * sout, sout, nb, true, ws, s);
-    }
+    for_tiles(c, rescale_ws_rows(level, polys), batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
+        rescale(c, level, polys, in + (size_t)b0 * sin, sin, out + (size_t)b0 * sout, sout, nb, true, ws, st);
+    });
 }
 
 void ckks_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u64* out, int batch, long long sin,
@@ -183,17 +195,14 @@ void ckks_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u6
     const long long N = c.n;
     const int L = level + 1;
     const u32* perm = c.ntt_perm(g);
-    const size_t rows = ks_ws_rows(c, level) + 2 * (size_t)L;
-    const int tb = pick_tile(c, rows, batch);
-    u64* ws = c.workspace(rows * N * tb, s);
-    u64* p = ws + ks_ws_rows(c, level) * N * tb;
+    const size_t ks_rows = ks_ws_rows(c, level);
     const long long sp = 2LL * L * N;
-    for (int b0 = 0; b0 < batch; b0 += tb) {
-        const int nb = std::min(tb, batch - b0);
+    for_tiles(c, ks_rows + 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
+        u64* p = ws + ks_rows * N * tb;
         const u64* ct = in + (size_t)b0 * sin;
-        key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, ct, sin, L, 1, nb, ws, s);
-        launch_permute_ntt(c, perm, p, sp, out + (size_t)b0 * sout, sout, 2 * L, nb, s);
-    }
+        key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, ct, sin, L, 1, nb, ws, st);
+        launch_permute_ntt(c, perm, p, sp, out + (size_t)b0 * sout, sout, 2 * L, nb, st);
+    });
 }
 
 void ckks_mult_relin_rescale(Context& c, int level, const u64* a, const u64* b, const Key& rlk, u64* out, int batch,
@@ -203,19 +212,15 @@ void ckks_mult_relin_rescale(Context& c, int level, const u64* a, const u64* b, 
     const int L = level + 1;
     const size_t r_d3 = 3 * (size_t)L, r_r2 = 2 * (size_t)L;
     const size_t r_shared = std::max(ks_ws_rows(c, level), rescale_ws_rows(level, 2));
-    const size_t rows = r_d3 + r_r2 + r_shared;
-    const int tb = pick_tile(c, rows, batch);
-    u64* ws = c.workspace(rows * N * tb, s);
-    u64* d3 = ws;
-    u64* r2 = d3 + r_d3 * N * tb;
-    u64* sub = r2 + r_r2 * N * tb;
     const long long sd = 3LL * L * N, sr = 2LL * L * N;
-    for (int b0 = 0; b0 < batch; b0 += tb) {
-        const int nb = std::min(tb, batch - b0);
-        launch_tensor(c, a + (size_t)b0 * sa, b + (size_t)b0 * sb, d3, nb, sa, sb, sd, L, rm_seq(L), s);
-        key_switch(c, level, d3 + 2LL * L * N, sd, rlk, r2, sr, d3, sd, L, 2, nb, sub, s);
-        rescale(c, level, 2, r2, sr, out + (size_t)b0 * so, so, nb, true, sub, s);
-    }
+    for_tiles(c, r_d3 + r_r2 + r_shared, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
+        u64* d3 = ws;
+        u64* r2 = d3 + r_d3 * N * tb;
+        u64* sub = r2 + r_r2 * N * tb;
+        launch_tensor(c, a + (size_t)b0 * sa, b + (size_t)b0 * sb, d3, nb, sa, sb, sd, L, rm_seq(L), st);
+        key_switch(c, level, d3 + 2LL * L * N, sd, rlk, r2, sr, d3, sd, L, 2, nb, sub, st);
+        rescale(c, level, 2, r2, sr, out + (size_t)b0 * so, so, nb, true, sub, st);
+    });
 }
 
 void drop_level(Context& c, int level, int polys, const u64* in, u64* out, int batch, long long sin, long long sout,
@@ -238,19 +243,13 @@ void poly_addsub(Context& c, int op, int level, int polys, const u64* a, const u
 static int bfv_aux_limbs(const Context& c, int level) { return bfv_aux_count(c.T.mod.data(), level + 1, c.logn); }
 
 void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int batch, long long sa, long long sb,
-              long long sd, hipStream_t s) {
+              long long sd, hipStream_t s0) {
     LSA_REQUIRE(c.algo == LSA_ALGO_BFV, "context is not BFV");
     LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
     const long long N = c.n;
     const int L = level + 1, M = bfv_aux_limbs(c, level), T2 = L + M;
     LSA_REQUIRE(M <= c.nmul, "auxiliary basis too small");
     const size_t rows = 2 * 2 * (size_t)T2 + 3 * (size_t)T2 + 3 * (size_t)M;
-    const int tb = pick_tile(c, rows, batch);
-    u64* ws = c.workspace(rows * N * tb, s);
-    u64* ea = ws;
-    u64* eb = ea + (size_t)tb * 2 * T2 * N;
-    u64* d = eb + (size_t)tb * 2 * T2 * N;
-    u64* ext = d + (size_t)tb * 3 * T2 * N;
     const long long s_e = 2LL * T2 * N, s_d = 3LL * T2 * N, s_x = 3LL * M * N;
     std::vector<int> qmods, amods;
     RowMap rmT;
@@ -286,8 +285,11 @@ void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int ba
     const u64* kQinv = c.const_vec("bfv_qinv" + std::to_string(L), amods, qinv);
     const u64* kT = c.const_vec("bfv_t" + std::to_string(L), qmods, tq);
 
-    for (int b0 = 0; b0 < batch; b0 += tb) {
-        const int nb = std::min(tb, batch - b0);
+    for_tiles(c, rows, batch, s0, [&](int nb, int b0, u64* ws, int tb, hipStream_t s) {
+        u64* ea = ws;
+        u64* eb = ea + (size_t)tb * 2 * T2 * N;
+        u64* d = eb + (size_t)tb * 2 * T2 * N;
+        u64* ext = d + (size_t)tb * 3 * T2 * N;
         const u64* srcs[2] = {a + (size_t)b0 * sa, b + (size_t)b0 * sb};
         const long long ss[2] = {sa, sb};
         u64* es[2] = {ea, eb};
@@ -314,7 +316,7 @@ void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int ba
         for (int k = 0; k < 3; k++)
             launch_baseconv(c, kAQ, rAQ, d + ((size_t)k * T2 + L) * N, o3 + (size_t)k * L * N, nb, s_d, sd, s);
         launch_sub_mul_general(c, 3, L, lmQ, kT, o3, sd, L, nullptr, 0, 0, nullptr, 0, 0, 0, o3, sd, L, nb, s);
-    }
+    });
 }
 
 // key switch of a coefficient-domain polynomial: NTT in, INTT out
@@ -333,17 +335,14 @@ void bfv_relin(Context& c, int level, const u64* d3, const Key& rlk, u64* out, i
                hipStream_t s) {
     const long long N = c.n;
     const int L = level + 1;
-    const size_t rows = ks_ws_rows(c, level) + L + 2 * (size_t)L;
-    const int tb = pick_tile(c, rows, batch);
-    u64* ws = c.workspace(rows * N * tb, s);
-    u64* p = ws + (ks_ws_rows(c, level) + L) * N * tb;
+    const size_t ks_rows = ks_ws_rows(c, level) + L;
     const long long sp = 2LL * L * N;
-    for (int b0 = 0; b0 < batch; b0 += tb) {
-        const int nb = std::min(tb, batch - b0);
+    for_tiles(c, ks_rows + 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
+        u64* p = ws + ks_rows * N * tb;
         const u64* d = d3 + (size_t)b0 * sd;
-        bfv_key_switch(c, level, d + 2LL * L * N, sd, rlk, p, sp, nb, ws, s);
-        launch_elementwise(c, EW_ADD, d, p, out + (size_t)b0 * so, nb, sd, sp, so, 2 * L, rm_seq(L), s);
-    }
+        bfv_key_switch(c, level, d + 2LL * L * N, sd, rlk, p, sp, nb, ws, st);
+        launch_elementwise(c, EW_ADD, d, p, out + (size_t)b0 * so, nb, sd, sp, so, 2 * L, rm_seq(L), st);
+    });
 }
 
 void bfv_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u64* out, int batch, long long sin,
@@ -351,29 +350,22 @@ void bfv_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u64
     const long long N = c.n;
     const int L = level + 1;
     const u32* perm = c.coeff_perm(g);
-    const size_t rows = ks_ws_rows(c, level) + L + 2 * (size_t)L;
-    const int tb = pick_tile(c, rows, batch);
-    u64* ws = c.workspace(rows * N * tb, s);
-    u64* p = ws + (ks_ws_rows(c, level) + L) * N * tb;
+    const size_t ks_rows = ks_ws_rows(c, level) + L;
     const long long sp = 2LL * L * N;
-    for (int b0 = 0; b0 < batch; b0 += tb) {
-        const int nb = std::min(tb, batch - b0);
+    for_tiles(c, ks_rows + 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
+        u64* p = ws + ks_rows * N * tb;
         const u64* ct = in + (size_t)b0 * sin;
-        bfv_key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, nb, ws, s);
-        launch_elementwise(c, EW_ADD, p, ct, p, nb, sp, sin, sp, L, rm_seq(L), s);  // p0 += c0
-        launch_permute_coeff(c, perm, p, sp, out + (size_t)b0 * sout, sout, 2 * L, rm_seq(L), nb, s);
-    }
+        bfv_key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, nb, ws, st);
+        launch_elementwise(c, EW_ADD, p, ct, p, nb, sp, sin, sp, L, rm_seq(L), st);  // p0 += c0
+        launch_permute_coeff(c, perm, p, sp, out + (size_t)b0 * sout, sout, 2 * L, rm_seq(L), nb, st);
+    });
 }
 
 void bfv_rescale(Context& c, int level, int polys, const u64* in, u64* out, int batch, long long sin, long long sout,
                  hipStream_t s) {
-    const size_t rows = rescale_ws_rows(level, polys);
-    const int tb = pick_tile(c, rows, batch);
-    u64* ws = c.workspace(rows * c.n * tb, s);
-    for (int b0 = 0; b0 < batch; b0 += tb) {
-        const int nb = std::min(tb, batch - b0);
-        rescale(c, level, polys, in + (size_t)b0 * sin, sin, out + (size_t)b0 * sout, sout, nb, false, ws, s);
-    }
+    for_tiles(c, rescale_ws_rows(level, polys), batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
+        rescale(c, level, polys, in + (size_t)b0 * sin, sin, out + (size_t)b0 * sout, sout, nb, false, ws, st);
+    });
 }
 
 }  // namespace lsa
