@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--ntt-chunk-mib", type=int, default=-1, help="Infinity-Cache chunk of two-pass NTTs (-1 = default)")
     ap.add_argument("--int-ntt", action="store_true", help="force the integer butterfly engine (A/B)")
     ap.add_argument("--single-stream", action="store_true", help="disable dual-stream tile overlap (A/B)")
+    ap.add_argument("--no-fuse", action="store_true", help="separate ModDown/rescale tail kernels (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=5)
     return ap.parse_args()
@@ -155,6 +156,8 @@ def main():
         ctx.set_fp64_ntt(False)
     if args.single_stream:
         check(L_.lsa_set_dual_stream(ctx.h, 0))
+    if args.no_fuse:
+        check(L_.lsa_set_fuse_tails(ctx.h, 0))
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)

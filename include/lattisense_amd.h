@@ -122,6 +122,9 @@ int lsa_set_fp64_ntt(lsa_context ctx, int enable);
 /* 1 (default): alternate tiles of a batched operator run on the caller's stream and on an internal auxiliary stream
  * (fork/join with events inside the call), so two independent tiles overlap; 0: everything on the caller's stream. */
 int lsa_set_dual_stream(lsa_context ctx, int enable);
+/* 1 (default): the ModDown and rescale element-wise tails run inside the NTT kernel's load/store phases; 0: separate
+ * kernels (A/B measurement; identical results). */
+int lsa_set_fuse_tails(lsa_context ctx, int enable);
 /* Two-pass NTTs (N > 2^12) run both passes over a chunk of at most `mib` MiB of limbs before moving on, so that the
  * second pass is served by the 256 MiB Infinity Cache (0 = one launch per pass over the whole batch). */
 int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib);

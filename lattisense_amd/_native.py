@@ -74,6 +74,7 @@ SIGNATURES = {
     "lsa_set_tile_batch": (c_int, [c_vp, c_int]),
     "lsa_set_fp64_ntt": (c_int, [c_vp, c_int]),
     "lsa_set_dual_stream": (c_int, [c_vp, c_int]),
+    "lsa_set_fuse_tails": (c_int, [c_vp, c_int]),
     "lsa_set_ntt_chunk_mib": (c_int, [c_vp, c_int]),
     "lsa_profile_begin": (c_int, [c_vp, c_int]),
     "lsa_profile_end": (c_int, [c_vp]),

@@ -332,6 +332,9 @@ int lsa_profile_read(lsa_context ctx, int kind, double* total_ms, double* total_
     });
 }
 
+int lsa_set_fuse_tails(lsa_context ctx, int enable) {
+    return guard([&] { C(ctx).fuse_tails = enable ? 1 : 0; });
+}
 int lsa_set_dual_stream(lsa_context ctx, int enable) {
     return guard([&] { C(ctx).dual_stream = enable ? 1 : 0; });
 }

@@ -225,6 +225,32 @@ const u32* Context::coeff_perm(u64 g) {
     return d;
 }
 
+// P^-1 mod q_i for i <= level (ModDown tail), Montgomery form
+const u64* Context::pinv_vec(int level) {
+    const int L = level + 1;
+    std::vector<int> mods(L);
+    std::vector<u64> pinv(L);
+    for (int i = 0; i < L; i++) {
+        mods[i] = i;
+        u64 q = T.mod[i], pr = 1;
+        for (int l = 0; l < np; l++) pr = mul_mod_host(pr, T.mod[p_mod(l)] % q, q);
+        pinv[i] = inv_mod(pr, q);
+    }
+    return const_vec("pinv" + std::to_string(L), mods, pinv);
+}
+
+// q_level^-1 mod q_i for i < level (rescale tail), Montgomery form
+const u64* Context::qlinv_vec(int level) {
+    std::vector<int> mods(level);
+    std::vector<u64> v(level);
+    const u64 ql = T.mod[level];
+    for (int i = 0; i < level; i++) {
+        mods[i] = i;
+        v[i] = inv_mod(ql % T.mod[i], T.mod[i]);
+    }
+    return const_vec("qlinv" + std::to_string(level), mods, v);
+}
+
 const u64* Context::const_vec(const std::string& name, const std::vector<int>& mods, const std::vector<u64>& vals) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = consts.find(name);

@@ -41,6 +41,23 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(Ntt
 #if LSA_NTT_TILES_PER_WG == 1
     const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
     if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
+#if defined(LSA_NTT_STAGGER)
+    // Workgroups of one launch have identical phase lengths and start together, so the 3-4 co-resident ones run their
+    // HBM phase and their butterfly phase in lockstep (measured: kernel time == copy-only time + compute-only time).
+    // Delay the workgroups that share a CU (blockIdx 256 apart in the first dispatch wave) by thirds of a tile period once.
+    {
+        const int phase = blockIdx.x < 768 ? (int)(blockIdx.x >> 8) : 0;   // first dispatch wave only
+        for (int i = 0; i < phase * LSA_NTT_STAGGER; i++) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
+#if defined(LSA_NTT_DIAG_COMPUTE_ONLY)   // diagnostic build: butterflies on synthetic LDS contents, no global traffic
+    for (int i = tid; i < (1 << a.tau); i += LSA_NTT_THREADS)
+        lds[lds_addr(i)] = bc.fp ? d_to_bits((double)(i * 7 + 1)) : (u64)(i * 7 + 1);
+    __syncthreads();
+    ntt_butterfly_phases(a, bc, tid, lds);
+    if (lds[lds_addr(tid)] == 0x123456789abcull) a.dst[bc.base_dst + tid] = 1;   // keeps the work alive
+    return;
+#endif
     ntt_phase_load(a, bc, tid, lds);
     __syncthreads();
 #if defined(LSA_NTT_DIAG_COPY_ONLY)   // diagnostic build: data movement of the pass structure without butterflies
@@ -84,7 +101,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch
 }
 
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
-                const RowMap& rm, bool inverse, hipStream_t s) {
+                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz) {
     if (batch <= 0 || rows <= 0) return;
     LSA_REQUIRE(rm.period >= 1 && rm.period <= LSA_MAX_PERIOD, "ntt: bad row-map period");
     NttPassArgs a{};
@@ -96,6 +113,27 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
     a.twd = inverse ? c.d_psiinv_d : c.d_psi_d;
     a.scaled = c.d_scale_d;
     a.allow_fp64 = c.fp64_ntt;
+    if (fz) {
+        LSA_REQUIRE(!inverse, "fused tails exist for forward transforms only");
+        LSA_REQUIRE(LSA_NTT_TILES_PER_WG == 1 || !fz->pro, "fused prologue needs the non-pipelined kernel");
+        a.fz_epi = fz->epi;
+        a.fz_pro = fz->pro;
+        a.fz_limbs = fz->limbs;
+        a.fz_base_polys = fz->base_polys;
+        a.fz_ql_mod = fz->ql_mod;
+        a.fz_a = fz->a;
+        a.fz_a_stride = fz->a_stride;
+        a.fz_a_rpp = fz->a_rpp;
+        a.fz_base = fz->base;
+        a.fz_base_stride = fz->base_stride;
+        a.fz_base_rpp = fz->base_rpp;
+        a.fz_k = fz->k;
+        a.fz_out = fz->out;
+        a.fz_out_stride = fz->out_stride;
+        a.fz_out_rpp = fz->out_rpp;
+        a.fz_last = fz->last;
+        a.fz_last_stride = fz->last_stride;
+    }
     a.period = rm.period;
     for (int i = 0; i < rm.period; i++) {
         LSA_REQUIRE(rm.mod_of[i] == LSA_ROW_SKIP || rm.mod_of[i] < c.nmod, "ntt: modulus index out of range");

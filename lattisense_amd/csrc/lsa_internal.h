@@ -79,6 +79,7 @@ struct Context {
     double* d_scale_d = nullptr;
     int fp64_ntt = 1;               // use the FP64 butterfly engine for limbs with q < 2^47
     int tile_batch = 0;
+    int fuse_tails = 1;             // ModDown / rescale element-wise tails fused into the NTT load/store phases
     int dual_stream = 1;            // overlap alternate tiles of an operator on an auxiliary stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -118,6 +119,8 @@ struct Context {
     int p_mod(int i) const { return nq + i; }
     int aux_mod(int i) const { return nq + np + i; }
     const BaseConvPlan* baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered);
+    const u64* pinv_vec(int level);
+    const u64* qlinv_vec(int level);
     const u32* ntt_perm(u64 g);
     const u32* coeff_perm(u64 g);
     // per-modulus constant vector on device, Montgomery form, built by `gen(mod_index)`
@@ -166,8 +169,24 @@ struct RowMap {   // rows of a batch item -> modulus index (0xFF = skip)
 
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch_stride, int rows, const RowMap& rm,
                 bool inverse, hipStream_t s);
+// element-wise work fused into a forward transform's first-pass load / last-pass store (see NttPassArgs::fz_*)
+struct NttFusion {
+    int epi = 0, pro = 0, limbs = 1, base_polys = 0, ql_mod = 0;
+    const u64* a = nullptr;
+    long long a_stride = 0;
+    int a_rpp = 0;
+    const u64* base = nullptr;
+    long long base_stride = 0;
+    int base_rpp = 0;
+    const u64* k = nullptr;
+    u64* out = nullptr;
+    long long out_stride = 0;
+    int out_rpp = 0;
+    const u64* last = nullptr;
+    long long last_stride = 0;
+};
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
-                const RowMap& rm, bool inverse, hipStream_t s);
+                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz = nullptr);
 
 // limb-wise binary/unary ops on [batch][rows][N]; row r uses modulus rm.mod_of[r % period]
 enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MUL = 3 };

@@ -58,6 +58,20 @@ struct NttPassArgs {
     int final_reduce;     // store fully reduced [0,q)
     int allow_fp64;       // 0 forces the integer engine for every limb
     int period;           // row r uses modulus mod_of[r % period]
+    // ---- fused element-wise tails (rows of the transformed buffer are [poly][fz_limbs]):
+    // epilogue of the LAST pass of a forward transform, replaces the plain store of the transformed value v:
+    //   fz_epi = 1:  out[poly][limb] = (fz_a[poly][limb] - v) * fz_k[limb]  (+ fz_base[poly][limb] if poly < fz_base_polys)
+    //                (ModDown tail: (acc_Q - conv) * P^-1 + d;   rescale tail: (c - t) * q_l^-1)
+    // prologue of the FIRST pass, replaces the plain load:
+    //   fz_pro = 1:  in = ((fz_last[poly] + h) mod q_l) mod q_limb - (h mod q_limb),  h = (q_l - 1)/2  (rescale head)
+    int fz_epi, fz_pro, fz_limbs, fz_base_polys, fz_ql_mod;
+    int fz_a_rpp, fz_base_rpp, fz_out_rpp;
+    const u64* fz_a;
+    const u64* fz_base;
+    const u64* fz_k;
+    u64* fz_out;
+    const u64* fz_last;
+    long long fz_a_stride, fz_base_stride, fz_out_stride, fz_last_stride;
     unsigned char mod_of[LSA_MAX_PERIOD];
 };
 
@@ -70,6 +84,7 @@ struct NttBlockCtx {
     int tile;             // tile index inside the limb
     int mod;              // modulus index
     int fp;               // 1: FP64 engine
+    int b, row;           // batch item and row inside it
 };
 
 LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
@@ -82,6 +97,8 @@ LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
     c.base_src = (long long)b * a.src_stride + ((long long)row << a.logn);
     c.base_dst = (long long)b * a.dst_stride + ((long long)row << a.logn);
     c.mod = a.mod_of[row % a.period];
+    c.b = b;
+    c.row = row;
     c.fp = 0;
     if (c.mod != LSA_ROW_SKIP) c.fp = a.allow_fp64 && (a.mods[c.mod].q >> LSA_FP64_MAX_BITS) == 0 && a.mu <= 9;
     return c;
@@ -143,14 +160,23 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
         int l = 2 * i;
         int x = ntt_global_index(a, bc.tile, l);
         u64 v0, v1;
+        const u64* gp = g + x;
+        if (a.fz_pro && a.s_lo == 0)   // fused rescale head: the tile is derived from the (coefficient-domain) last limb
+            gp = a.fz_last + (long long)bc.b * a.fz_last_stride + ((long long)(bc.row / a.fz_limbs) << a.logn) + x;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g + x);
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(gp);
         v0 = v.x;
         v1 = v.y;
 #else
-        v0 = g[x];
-        v1 = g[x + 1];
+        v0 = gp[0];
+        v1 = gp[1];
 #endif
+        if (a.fz_pro && a.s_lo == 0) {
+            const ModDev ml = a.mods[a.fz_ql_mod], mi = a.mods[bc.mod];
+            const u64 h = (ml.q - 1) >> 1, hq = reduce_u64(h, mi);
+            v0 = sub_mod(reduce_u64(add_mod(v0, h, ml.q), mi), hq, mi.q);
+            v1 = sub_mod(reduce_u64(add_mod(v1, h, ml.q), mi), hq, mi.q);
+        }
         if (bc.fp) {  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact as doubles
             v0 = d_to_bits((double)v0);
             v1 = d_to_bits((double)v1);
@@ -221,14 +247,29 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
             v0 = csub(csub(v0, 2 * q), q);
             v1 = csub(csub(v1, 2 * q), q);
         }
+        u64* gp = g + x;
+        if (a.fz_epi && a.final_reduce) {   // fused tail: the transformed value is consumed here and never stored
+            const ModDev md = a.mods[bc.mod];
+            const int poly = bc.row / a.fz_limbs, limb = bc.row % a.fz_limbs;
+            const u64* pa = a.fz_a + (long long)bc.b * a.fz_a_stride + (((long long)poly * a.fz_a_rpp + limb) << a.logn) + x;
+            const u64 k = a.fz_k[limb];
+            v0 = mont_mul(sub_mod(pa[0], v0, q), k, q, md.qinv);
+            v1 = mont_mul(sub_mod(pa[1], v1, q), k, q, md.qinv);
+            if (a.fz_base && poly < a.fz_base_polys) {
+                const u64* pb = a.fz_base + (long long)bc.b * a.fz_base_stride + (((long long)poly * a.fz_base_rpp + limb) << a.logn) + x;
+                v0 = add_mod(v0, pb[0], q);
+                v1 = add_mod(v1, pb[1], q);
+            }
+            gp = a.fz_out + (long long)bc.b * a.fz_out_stride + (((long long)poly * a.fz_out_rpp + limb) << a.logn) + x;
+        }
 #if defined(__HIP_DEVICE_COMPILE__)
         ulonglong2 v;
         v.x = v0;
         v.y = v1;
-        *reinterpret_cast<ulonglong2*>(g + x) = v;
+        *reinterpret_cast<ulonglong2*>(gp) = v;
 #else
-        g[x] = v0;
-        g[x + 1] = v1;
+        gp[0] = v0;
+        gp[1] = v1;
 #endif
     }
 }

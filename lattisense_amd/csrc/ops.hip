@@ -105,8 +105,28 @@ static void key_switch(Context& c, int level, const u64* cx, long long scx, cons
         for (int h = 0; h < 2; h++)
             launch_baseconv(c, k, rows, acc + (size_t)h * T * N, conv + (size_t)h * L * N, nb, s_acc, s_conv, s);
     }
-    launch_ntt(c, conv, conv, nb, s_conv, 2 * L, rm_seq(L), false, s);
-    launch_moddown_final(c, level, acc, s_acc, T, conv, s_conv, base, sbase, base_rpp, base_polys, p, sp, nb, s);
+    if (c.fuse_tails) {
+        // forward NTT of conv with the ModDown tail fused into its last-pass store: the transformed conv is consumed in
+        // registers ((acc_Q - conv) * P^-1 + base) and never written
+        NttFusion fz;
+        fz.epi = 1;
+        fz.limbs = L;
+        fz.a = acc;
+        fz.a_stride = s_acc;
+        fz.a_rpp = T;
+        fz.base = base;
+        fz.base_stride = sbase;
+        fz.base_rpp = base_rpp;
+        fz.base_polys = base_polys;
+        fz.k = c.pinv_vec(level);
+        fz.out = p;
+        fz.out_stride = sp;
+        fz.out_rpp = L;
+        launch_ntt(c, conv, conv, nb, s_conv, s_conv, 2 * L, rm_seq(L), false, s, &fz);
+    } else {
+        launch_ntt(c, conv, conv, nb, s_conv, 2 * L, rm_seq(L), false, s);
+        launch_moddown_final(c, level, acc, s_acc, T, conv, s_conv, base, sbase, base_rpp, base_polys, p, sp, nb, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ rescale
@@ -128,6 +148,26 @@ static void rescale(Context& c, int level, int polys, const u64* in, long long s
         rm.period = 1;
         rm.mod_of[0] = (unsigned char)level;
         launch_ntt(c, last, last, nb, s_last, polys, rm, true, s);
+    }
+    if (ntt_domain && c.fuse_tails) {
+        // one forward NTT over the level limbs of every polynomial: its first-pass load derives the tile from the last limb
+        // (centred remainder, reduced to the target prime), its last-pass store applies (c - t) * q_l^-1 -> out
+        NttFusion fz;
+        fz.pro = 1;
+        fz.epi = 1;
+        fz.limbs = level;
+        fz.ql_mod = level;
+        fz.last = last;
+        fz.last_stride = s_last;
+        fz.a = in;
+        fz.a_stride = sin;
+        fz.a_rpp = L;
+        fz.k = c.qlinv_vec(level);
+        fz.out = out;
+        fz.out_stride = sout;
+        fz.out_rpp = level;
+        launch_ntt(c, tmp, tmp, nb, s_tmp, s_tmp, polys * level, rm_seq(level), false, s, &fz);
+        return;
     }
     launch_rescale_prep(c, level, polys, last, s_last, tmp, s_tmp, nb, s);
     if (ntt_domain) launch_ntt(c, tmp, tmp, nb, s_tmp, polys * level, rm_seq(level), false, s);

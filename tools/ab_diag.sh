@@ -1,5 +1,5 @@
 #!/bin/bash
-for flags in "" "-DLSA_NTT_DIAG_COPY_ONLY" "-DLSA_NTT_DIAG_NO_TWIDDLE_LOADS"; do
+for flags in "$@"; do
   LSA_EXTRA_FLAGS="$flags" python lattisense_amd/build.py --force > /dev/null 2>&1
   echo "== flags=$flags"
   python tools/probe_engines.py 2>/dev/null | tr -d '\n ' ; echo
