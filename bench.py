@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
     ap.add_argument("--ntt-chunk-mib", type=int, default=-1, help="Infinity-Cache chunk of two-pass NTTs (-1 = default)")
     ap.add_argument("--int-ntt", action="store_true", help="force the integer butterfly engine (A/B)")
-    ap.add_argument("--single-stream", action="store_true", help="disable dual-stream tile overlap (A/B)")
+    ap.add_argument("--dual-stream", action="store_true", help="overlap alternate tiles on an auxiliary stream (A/B)")
     ap.add_argument("--no-fuse", action="store_true", help="separate ModDown/rescale tail kernels (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=5)
@@ -154,8 +154,8 @@ def main():
         check(L_.lsa_set_ntt_chunk_mib(ctx.h, args.ntt_chunk_mib))
     if args.int_ntt:
         ctx.set_fp64_ntt(False)
-    if args.single_stream:
-        check(L_.lsa_set_dual_stream(ctx.h, 0))
+    if args.dual_stream:
+        check(L_.lsa_set_dual_stream(ctx.h, 1))
     if args.no_fuse:
         check(L_.lsa_set_fuse_tails(ctx.h, 0))
 
@@ -302,7 +302,7 @@ def cpu_baseline(workload, cfg):
         for j, m in enumerate(qs + cfg["p"]):
             key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
     a, b = rand_ct(), rand_ct()
-    per_thread = 1
+    per_thread = 40 if workload == "ntt" else 1   # ~1-2 s of CPU work per thread either way
     done = []
 
     def work():

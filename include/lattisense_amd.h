@@ -119,8 +119,9 @@ int lsa_set_tile_batch(lsa_context ctx, int tile_batch);
 /* NTT butterfly engine for limbs with q < 2^47: 1 (default) = exact FP64-FMA butterflies, 0 = integer Montgomery for
  * every limb.  Both produce identical residues; the switch exists for A/B measurement and parity tests. */
 int lsa_set_fp64_ntt(lsa_context ctx, int enable);
-/* 1 (default): alternate tiles of a batched operator run on the caller's stream and on an internal auxiliary stream
- * (fork/join with events inside the call), so two independent tiles overlap; 0: everything on the caller's stream. */
+/* 1: alternate tiles of a batched operator run on the caller's stream and on an internal auxiliary stream (fork/join
+ * with events inside the call), so two independent tiles overlap (+5 % measured); 0 (default): everything on the
+ * caller's stream, which keeps per-kernel timings attributable. */
 int lsa_set_dual_stream(lsa_context ctx, int enable);
 /* 1 (default): the ModDown and rescale element-wise tails run inside the NTT kernel's load/store phases; 0: separate
  * kernels (A/B measurement; identical results). */

@@ -80,7 +80,8 @@ struct Context {
     int fp64_ntt = 1;               // use the FP64 butterfly engine for limbs with q < 2^47
     int tile_batch = 0;
     int fuse_tails = 1;             // ModDown / rescale element-wise tails fused into the NTT load/store phases
-    int dual_stream = 1;            // overlap alternate tiles of an operator on an auxiliary stream
+    int dual_stream = 0;            // 1: overlap alternate tiles of an operator on an auxiliary stream (+5% throughput,
+                                    // but per-kernel timings then include the co-running kernel; off for clean accounting)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void fork_aux(hipStream_t s);   // aux stream waits for everything enqueued on s so far
