@@ -175,8 +175,9 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
 struct EwArgs {
     const u64* a;
     const u64* b;
+    const u64* acc;   // EW_MUL only: optional accumulator operand
     u64* out;
-    long long sa, sb, so;
+    long long sa, sb, so, sacc;
     const ModDev* mods;
     int rows, logn, op, period;
     unsigned char mod_of[LSA_MAX_PERIOD];
@@ -216,6 +217,11 @@ __global__ __launch_bounds__(TPB) void k_elementwise(EwArgs g) {
         } else {
             r0 = mul_mod(va.x, vb.x, m);
             r1 = mul_mod(va.y, vb.y, m);
+            if (g.acc) {   // multiply-accumulate: out = acc + a*b
+                const ulonglong2 vc = ld2(g.acc + b * g.sacc + off);
+                r0 = add_mod(r0, vc.x, m.q);
+                r1 = add_mod(r1, vc.y, m.q);
+            }
         }
     }
     st2(g.out + b * g.so + off, r0, r1);
@@ -237,8 +243,16 @@ static dim3 ew_grid(const Context& c, int rows, int batch) {
 
 void launch_elementwise(Context& c, EwOp op, const u64* a, const u64* b, u64* out, int batch, long long sa, long long sb,
                         long long so, int rows, const RowMap& rm, hipStream_t s) {
+    launch_muladd(c, op, a, b, nullptr, 0, out, batch, sa, sb, so, rows, rm, s);
+}
+
+// out = op(a, b) (+ acc for EW_MUL when acc != nullptr)
+void launch_muladd(Context& c, EwOp op, const u64* a, const u64* b, const u64* acc, long long sacc, u64* out, int batch,
+                   long long sa, long long sb, long long so, int rows, const RowMap& rm, hipStream_t s) {
     if (batch <= 0 || rows <= 0) return;
     EwArgs g{};
+    g.acc = acc;
+    g.sacc = sacc;
     g.a = a;
     g.b = b;
     g.out = out;
@@ -816,6 +830,78 @@ void launch_to_mont(Context& c, u64* data, int rows, const RowMap& rm, hipStream
     g.logn = c.logn;
     fill_rowmap(g.mod_of, g.period, rm, c.nmod);
     hipLaunchKernelGGL(k_to_mont, ew_grid(c, rows, 1), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ ring-t plaintext lifts (K11)
+// A ring-t plaintext is one coefficient-domain limb (plug-in/lattigo/acc/c_struct_import_export.go:179-184).
+//   mode 0 (CKKS): residues mod q_src as CENTRED integers -> every q_i
+//   mode 1 (BFV multiply): message mod t used directly as residues mod q_i
+//   mode 2 (BFV add/sub): scale up by Q/t with rounding: u = (m*[Q]_t + t/2) mod t, out_i = (u - t/2) * (-t^-1) mod q_i
+struct LiftArgs {
+    const u64* pt;
+    u64* out;
+    long long spt, sout;
+    const ModDev* mods;
+    const u64* neg_tinv;   // mode 2: -(t^-1) mod q_i, Montgomery form
+    u64 t, qmodt;
+    int mode, src_mod, logn, limbs;
+};
+
+__global__ __launch_bounds__(TPB) void k_lift_ringt(LiftArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int limb = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const long long b = blockIdx.y;
+    const ModDev mi = g.mods[limb];
+    const ulonglong2 v = ld2(g.pt + b * g.spt + x);
+    u64 r[2] = {v.x, v.y};
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        if (g.mode == 0) {
+            const u64 q0 = g.mods[g.src_mod].q;
+            r[e] = r[e] > (q0 >> 1) ? neg_mod(reduce_u64(q0 - r[e], mi), mi.q) : reduce_u64(r[e], mi);
+        } else if (g.mode == 1) {
+            r[e] = reduce_u64(r[e], mi);
+        } else {
+            const u64 thalf = g.t >> 1;
+            const u64 u = ((r[e] % g.t) * g.qmodt + thalf) % g.t;   // t < 2^32: the product fits 64 bits
+            r[e] = mont_mul(sub_mod(reduce_u64(u, mi), reduce_u64(thalf, mi), mi.q), g.neg_tinv[limb], mi.q, mi.qinv);
+        }
+    }
+    st2(g.out + b * g.sout + ((long long)limb << g.logn) + x, r[0], r[1]);
+}
+
+void launch_lift_ringt(Context& c, int mode, int level, const u64* pt, long long spt, u64* out, long long sout, int batch,
+                       hipStream_t s) {
+    if (batch <= 0) return;
+    const int L = level + 1;
+    LiftArgs g{};
+    g.pt = pt;
+    g.out = out;
+    g.spt = spt;
+    g.sout = sout;
+    g.mods = c.d_mods;
+    g.mode = mode;
+    g.src_mod = 0;
+    g.logn = c.logn;
+    g.limbs = L;
+    if (mode == 2) {
+        LSA_REQUIRE(c.t > 1 && c.t < (1ull << 32), "ring-t scale-up needs a plaintext modulus below 2^32");
+        g.t = c.t;
+        u64 qm = 1 % c.t;
+        for (int i = 0; i < L; i++) qm = mul_mod_host(qm, c.T.mod[i] % c.t, c.t);
+        g.qmodt = qm;
+        std::vector<int> mods(L);
+        std::vector<u64> v(L);
+        for (int i = 0; i < L; i++) {
+            mods[i] = i;
+            v[i] = c.T.mod[i] - inv_mod(c.t % c.T.mod[i], c.T.mod[i]);
+        }
+        g.neg_tinv = c.const_vec("neg_tinv" + std::to_string(L), mods, v);
+    }
+    ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * (1 + L) * batch, s);
+    hipLaunchKernelGGL(k_lift_ringt, ew_grid(c, L, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
 

@@ -193,6 +193,12 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
 enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MUL = 3 };
 void launch_elementwise(Context& c, EwOp op, const u64* a, const u64* b, u64* out, int batch, long long sa,
                         long long sb, long long so, int rows, const RowMap& rm, hipStream_t s);
+void launch_muladd(Context& c, EwOp op, const u64* a, const u64* b, const u64* acc, long long sacc, u64* out, int batch,
+                   long long sa, long long sb, long long so, int rows, const RowMap& rm, hipStream_t s);
+// ring-t plaintext limb -> [level+1][N] residues: mode 0 centred lift from q_0 (CKKS), 1 direct (BFV multiply),
+// 2 scale-up by Q/t (BFV add/sub)
+void launch_lift_ringt(Context& c, int mode, int level, const u64* pt, long long spt, u64* out, long long sout, int batch,
+                       hipStream_t s);
 // CKKS/BFV tensor: a,b [2][T][N] -> d [3][T][N]; limb i uses modulus rm.mod_of[i]
 void launch_tensor(Context& c, const u64* a, const u64* b, u64* d, int batch, long long sa, long long sb, long long sd,
                    int limbs, const RowMap& rm, hipStream_t s);

@@ -145,15 +145,11 @@ void bind_gpu_executor(ComputeNode& node, Algo algorithm) {
         if (!in->fhe_prop) throw std::runtime_error("FHE property not found for input node " + std::to_string(in->index));
     switch (op) {
         case OperationType::ADD:
-        case OperationType::SUB:
-            if (node.input_nodes.size() == 2 && is_plain_node(node.input_nodes[1]) && is_ringt_node(node.input_nodes[1]))
-                unsupported("ring-t plaintext operands are scheduled for a later round");
-            break;
+        case OperationType::SUB: break;   // ct+-ct, ct+-pt, ct+-ring-t pt
         case OperationType::MULTIPLY:
-            if (node.input_nodes.size() == 2 && is_plain_node(node.input_nodes[1])) {
-                if (is_ringt_node(node.input_nodes[1])) unsupported("ring-t plaintext operands are scheduled for a later round");
-                if (algorithm == ALGO_BFV) throw std::runtime_error("Multiply with plaintext only supported for CKKS scheme");
-            }
+            if (node.input_nodes.size() == 2 && is_plain_node(node.input_nodes[1]) && !is_ringt_node(node.input_nodes[1]) &&
+                algorithm == ALGO_BFV)
+                throw std::runtime_error("Multiply with plaintext only supported for CKKS scheme");  // executors_gpu.cu:212
             break;
         case OperationType::NEGATE:
         case OperationType::RELINEARIZE:
@@ -167,7 +163,15 @@ void bind_gpu_executor(ComputeNode& node, Algo algorithm) {
             if (algorithm == ALGO_BFV) throw std::runtime_error("DROP_LEVEL only supported for CKKS scheme");
             break;
         case OperationType::MAC_WO_PARTIAL_SUM:
-        case OperationType::MAC_W_PARTIAL_SUM: unsupported("ct-pt multiply-accumulate is scheduled for a later round"); break;
+        case OperationType::MAC_W_PARTIAL_SUM: {
+            if (!node.fhe_prop->p) throw std::runtime_error("Sum count not found in FHE property");
+            const int n = node.fhe_prop->p->sum_cnt;
+            const size_t pt0 = (size_t)n + (op == OperationType::MAC_W_PARTIAL_SUM ? 1 : 0);
+            if (node.input_nodes.size() != pt0 + (size_t)n) unsupported("compressed plaintext blocks");
+            if (algorithm == ALGO_BFV && !is_ringt_node(node.input_nodes[pt0]))
+                throw std::runtime_error("Multiply with plaintext only supported for CKKS scheme");  // executors_gpu.cu:349,405
+            break;
+        }
         case OperationType::BOOTSTRAP: unsupported("bootstrapping is scheduled for a later round"); break;
         default: unsupported("unknown");
     }
@@ -466,6 +470,24 @@ struct fhe_task_handle_st {
         for (int i = 0; i < L; i++) rmL.mod_of[i] = (unsigned char)i;
 
         auto key_of = [&](int pos) -> const Key& { return std::any_cast<KeyP>(avail.at(n0->input_nodes[pos]->index))->key; };
+        // plaintext operand `pos` of every node as [m][L][N] limbs in the domain the operator needs.
+        //   full plaintext: used as loaded (CKKS: NTT domain; BFV: coefficient domain, already scaled)
+        //   ring-t plaintext (one limb): lifted per `ringt_mode` (kernels.hip k_lift_ringt), then NTT'd if `to_ntt`
+        auto plain_operand = [&](int pos, int ringt_mode, bool to_ntt) -> Operand {
+            if (!is_ringt_node(n0->input_nodes[pos])) return gather(c, s, nodes, pos, avail, (size_t)L * N);
+            Operand raw = gather(c, s, nodes, pos, avail, (size_t)N);
+            Operand o{nullptr, (long long)L * N, std::make_shared<Slab>((size_t)m * L * N)};
+            pending_free.push_back(o.keep);
+            launch_lift_ringt(c, ringt_mode, lvl, raw.ptr, raw.stride, o.keep->ptr, o.stride, m, s);
+            if (to_ntt) launch_ntt(c, o.keep->ptr, o.keep->ptr, m, o.stride, L, rmL, false, s);
+            o.ptr = o.keep->ptr;
+            return o;
+        };
+        auto temp = [&](size_t words) {
+            auto sl = std::make_shared<Slab>(words);
+            pending_free.push_back(sl);
+            return sl->ptr;
+        };
 
         switch (op) {
             case OperationType::ADD:
@@ -474,7 +496,9 @@ struct fhe_task_handle_st {
                 if (n0->input_nodes.size() == 1) {
                     launch_elementwise(c, ew, a.ptr, a.ptr, out, m, a.stride, a.stride, so, polys_in * L, rmL, s);
                 } else if (is_plain_node(n0->input_nodes[1])) {
-                    Operand b = gather(c, s, nodes, 1, avail, (size_t)L * N);
+                    // CKKS: plaintext limbs in the NTT domain (ring-t: centred lift + NTT); BFV: coefficient domain
+                    // (ring-t: scaled up by Q/t with rounding)
+                    Operand b = plain_operand(1, bfv ? 2 : 0, !bfv);
                     std::vector<int> rows(polys_in * L);
                     for (size_t i = 0; i < rows.size(); i++) rows[i] = (int)i;
                     launch_copy_rows(c, a.ptr, a.stride, out, so, polys_in * L, rows.data(), m, s);
@@ -489,11 +513,23 @@ struct fhe_task_handle_st {
                 launch_elementwise(c, EW_NEG, a.ptr, nullptr, out, m, a.stride, 0, so, polys_in * L, rmL, s);
                 break;
             case OperationType::MULTIPLY: {
-                if (n0->input_nodes.size() == 2 && is_plain_node(n0->input_nodes[1])) {  // CKKS ct * pt, both NTT domain
-                    Operand b = gather(c, s, nodes, 1, avail, (size_t)L * N);
-                    for (int p = 0; p < polys_in; p++)
-                        launch_elementwise(c, EW_MUL, a.ptr + (size_t)p * L * N, b.ptr, out + (size_t)p * L * N, m, a.stride,
-                                           b.stride, so, L, rmL, s);
+                if (n0->input_nodes.size() == 2 && is_plain_node(n0->input_nodes[1])) {
+                    if (!bfv) {  // CKKS ct * pt, both NTT domain (ring-t: centred lift + NTT first)
+                        Operand b = plain_operand(1, 0, true);
+                        for (int p = 0; p < polys_in; p++)
+                            launch_elementwise(c, EW_MUL, a.ptr + (size_t)p * L * N, b.ptr, out + (size_t)p * L * N, m,
+                                               a.stride, b.stride, so, L, rmL, s);
+                    } else {     // BFV ct * ring-t pt: NTT(ct) . NTT(pt as residues), back to coefficients
+                        Operand b = plain_operand(1, 1, true);
+                        std::vector<int> rows(polys_in * L);
+                        for (size_t i = 0; i < rows.size(); i++) rows[i] = (int)i;
+                        launch_copy_rows(c, a.ptr, a.stride, out, so, polys_in * L, rows.data(), m, s);
+                        launch_ntt(c, out, out, m, so, polys_in * L, rmL, false, s);
+                        for (int p = 0; p < polys_in; p++)
+                            launch_elementwise(c, EW_MUL, out + (size_t)p * L * N, b.ptr, out + (size_t)p * L * N, m, so,
+                                               b.stride, so, L, rmL, s);
+                        launch_ntt(c, out, out, m, so, polys_in * L, rmL, true, s);
+                    }
                     break;
                 }
                 Operand b = n0->input_nodes.size() == 1 ? a : gather(c, s, nodes, 1, avail, w_in);
@@ -528,6 +564,40 @@ struct fhe_task_handle_st {
                 LSA_REQUIRE(gel != 0, "Galois element missing on the key datum");
                 if (bfv) bfv_rotate(c, lvl, a.ptr, gel, key_of(1), out, m, a.stride, so, s);
                 else ckks_rotate(c, lvl, a.ptr, gel, key_of(1), out, m, a.stride, so, s);
+                break;
+            }
+            case OperationType::MAC_WO_PARTIAL_SUM:
+            case OperationType::MAC_W_PARTIAL_SUM: {
+                // inputs: ct_0..ct_{n-1}, (ct_partial,) pt_0..pt_{n-1}   (frontend/custom_task.py:1753-1836)
+                // out = sum_i ct_i * pt_i (+ ct_partial); mega_ag_executors_gpu.cu:294-408 does multiply_plain + add_inplace
+                const int n = n0->fhe_prop->p->sum_cnt;
+                const bool with_partial = op == OperationType::MAC_W_PARTIAL_SUM;
+                const int pt0 = n + (with_partial ? 1 : 0);
+                LSA_REQUIRE((int)n0->input_nodes.size() == pt0 + n, "MAC node: unexpected number of inputs");
+                const int rows = polys_in * L;
+                u64* tmp = bfv ? temp((size_t)m * w_in) : nullptr;
+                std::vector<int> all(rows);
+                for (int i = 0; i < rows; i++) all[i] = i;
+                for (int i = 0; i < n; i++) {
+                    Operand ci = i == 0 ? a : gather(c, s, nodes, i, avail, w_in);
+                    Operand pi = plain_operand(pt0 + i, bfv ? 1 : 0, true);
+                    const u64* cptr = ci.ptr;
+                    long long cstride = ci.stride;
+                    if (bfv) {  // accumulate in the NTT domain, one inverse transform at the end (linear => identical residues)
+                        launch_copy_rows(c, ci.ptr, ci.stride, tmp, (long long)w_in, rows, all.data(), m, s);
+                        launch_ntt(c, tmp, tmp, m, (long long)w_in, rows, rmL, false, s);
+                        cptr = tmp;
+                        cstride = (long long)w_in;
+                    }
+                    for (int p = 0; p < polys_in; p++)
+                        launch_muladd(c, EW_MUL, cptr + (size_t)p * L * N, pi.ptr, i == 0 ? nullptr : out + (size_t)p * L * N, so,
+                                      out + (size_t)p * L * N, m, cstride, pi.stride, so, L, rmL, s);
+                }
+                if (bfv) launch_ntt(c, out, out, m, so, rows, rmL, true, s);
+                if (with_partial) {
+                    Operand part = gather(c, s, nodes, n, avail, w_in);
+                    launch_elementwise(c, EW_ADD, out, part.ptr, out, m, so, part.stride, so, rows, rmL, s);
+                }
                 break;
             }
             default: throw Error(LSA_ERR_ARG, std::string("operation not implemented on this backend: ") + op_name(op));

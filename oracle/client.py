@@ -227,6 +227,17 @@ class Client:
         z = allv[k]
         return z if nslots is None else z[:nslots]
 
+    def ckks_encode_ringt(self, z, scale):
+        """ring-t plaintext: the scaled message polynomial as ONE limb mod q_0 (centred representation)"""
+        m = self.ckks_encode_coeffs(z, scale)
+        return np.array([int(x) % self.o.mod[0] for x in m], dtype=np.uint64)
+
+    def ckks_encode_ntt(self, z, lvl, scale):
+        """full CKKS plaintext: [lvl+1][N] NTT-domain limbs"""
+        m = self.ckks_encode_coeffs(z, scale)
+        return np.stack([self.o.ntt(i, np.array([int(x) % self.o.mod[i] for x in m], dtype=np.uint64))
+                         for i in range(lvl + 1)])
+
     def ckks_encrypt(self, z, lvl, scale):
         o = self.o
         m = self.ckks_encode_coeffs(z, scale)

@@ -615,3 +615,82 @@ void ora_bfv_mult_relin(const ora_ctx* c, int lvl, const u64* a, const u64* b,
     ora_bfv_relin(c, lvl, d3, rlk, klvl, out2);
     free(d3);
 }
+
+/* ------------------------------------------------------------------ ring-t plaintexts
+ * A ring-t plaintext is ONE coefficient-domain limb (abi: level 0, plug-in/lattigo/acc/c_struct_import_export.go:179-184):
+ *   CKKS: the scaled message reduced mod q_0  -> lifted as a CENTRED integer to every q_i, then NTT;
+ *   BFV : the message mod t.  multiply: used directly as residues mod q_i (Lattigo bfv mulPlaintextRingT);
+ *         add/sub: scaled up by Q/t with rounding (Lattigo bfv scaleUp): u = (m*[Q]_t + t/2) mod t,
+ *         out_i = (u - t/2) * (-t^-1) mod q_i  ==  round(m*Q/t) mod q_i. */
+void ora_lift_centered(const ora_ctx* c, int src_mi, int lvl, const u64* pt, u64* out) {
+    int n = c->n;
+    u64 q0 = c->mod[src_mi], half = q0 >> 1;
+    for (int i = 0; i <= lvl; i++) {
+        u64 qi = c->mod[i];
+        for (int x = 0; x < n; x++) {
+            u64 v = pt[x];
+            out[(size_t)i * n + x] = v > half ? submod(0, (q0 - v) % qi, qi) : v % qi;
+        }
+    }
+}
+
+void ora_bfv_scale_up(const ora_ctx* c, int lvl, const u64* pt, u64* out) {
+    int n = c->n;
+    u64 t = c->t, thalf = t >> 1;
+    u64 qmodt = 1 % t;
+    for (int i = 0; i <= lvl; i++) qmodt = ora_mulmod(qmodt, c->mod[i] % t, t);
+    for (int i = 0; i <= lvl; i++) {
+        u64 qi = c->mod[i];
+        u64 neg_tinv = qi - invmod(t % qi, qi);
+        u64 thalf_q = thalf % qi;
+        for (int x = 0; x < n; x++) {
+            u64 u = (ora_mulmod(pt[x] % t, qmodt, t) + thalf) % t;
+            out[(size_t)i * n + x] = ora_mulmod(submod(u % qi, thalf_q, qi), neg_tinv, qi);
+        }
+    }
+}
+
+/* op: 0 add, 1 sub, 2 mul.  ct [polys][L][N] NTT domain, pt ring-t limb mod q_0 */
+void ora_ckks_plain_ringt(const ora_ctx* c, int op, int lvl, int polys, const u64* ct, const u64* pt, u64* out) {
+    int n = c->n, L = lvl + 1;
+    u64* lift = (u64*)malloc(sizeof(u64) * L * n);
+    ora_lift_centered(c, 0, lvl, pt, lift);
+    for (int i = 0; i < L; i++) ora_ntt(c, i, lift + (size_t)i * n);
+    memcpy(out, ct, sizeof(u64) * polys * L * n);
+    for (int i = 0; i < L; i++) {
+        if (op == 0) ora_vec_add(c, i, ct + (size_t)i * n, lift + (size_t)i * n, out + (size_t)i * n);
+        else if (op == 1) ora_vec_sub(c, i, ct + (size_t)i * n, lift + (size_t)i * n, out + (size_t)i * n);
+        else
+            for (int p = 0; p < polys; p++)
+                ora_vec_mul(c, i, ct + ((size_t)p * L + i) * n, lift + (size_t)i * n, out + ((size_t)p * L + i) * n);
+    }
+    free(lift);
+}
+
+/* op: 0 add, 1 sub, 2 mul.  ct [polys][L][N] coefficient domain, pt ring-t limb mod t */
+void ora_bfv_plain_ringt(const ora_ctx* c, int op, int lvl, int polys, const u64* ct, const u64* pt, u64* out) {
+    int n = c->n, L = lvl + 1;
+    u64* tmp = (u64*)malloc(sizeof(u64) * L * n);
+    memcpy(out, ct, sizeof(u64) * polys * L * n);
+    if (op == 0 || op == 1) {
+        ora_bfv_scale_up(c, lvl, pt, tmp);
+        for (int i = 0; i < L; i++) {
+            if (op == 0) ora_vec_add(c, i, ct + (size_t)i * n, tmp + (size_t)i * n, out + (size_t)i * n);
+            else ora_vec_sub(c, i, ct + (size_t)i * n, tmp + (size_t)i * n, out + (size_t)i * n);
+        }
+    } else {
+        for (int i = 0; i < L; i++) {
+            u64 qi = c->mod[i];
+            u64* pn = tmp + (size_t)i * n;
+            for (int x = 0; x < n; x++) pn[x] = pt[x] % qi;
+            ora_ntt(c, i, pn);
+            for (int p = 0; p < polys; p++) {
+                u64* o = out + ((size_t)p * L + i) * n;
+                ora_ntt(c, i, o);
+                ora_vec_mul(c, i, o, pn, o);
+                ora_intt(c, i, o);
+            }
+        }
+    }
+    free(tmp);
+}

@@ -100,6 +100,12 @@ void ora_bfv_rescale(const ora_ctx* c, int lvl, const uint64_t* in2, int npoly, 
 void ora_bfv_mult_relin(const ora_ctx* c, int lvl, const uint64_t* a, const uint64_t* b,
                         const uint64_t* rlk, int klvl, uint64_t* out2);
 
+/* ring-t plaintext operands (one coefficient-domain limb): op 0 add, 1 sub, 2 mul */
+void ora_lift_centered(const ora_ctx* c, int src_mi, int lvl, const uint64_t* pt, uint64_t* out);
+void ora_bfv_scale_up(const ora_ctx* c, int lvl, const uint64_t* pt, uint64_t* out);
+void ora_ckks_plain_ringt(const ora_ctx* c, int op, int lvl, int polys, const uint64_t* ct, const uint64_t* pt, uint64_t* out);
+void ora_bfv_plain_ringt(const ora_ctx* c, int op, int lvl, int polys, const uint64_t* ct, const uint64_t* pt, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,9 @@ def lib():
             "ora_bfv_rotate": [vp, i, u64p, u, u64p, i, u64p],
             "ora_bfv_rescale": [vp, i, u64p, i, u64p],
             "ora_bfv_mult_relin": [vp, i, u64p, u64p, u64p, i, u64p],
+            "ora_ckks_plain_ringt": [vp, i, i, i, u64p, u64p, u64p],
+            "ora_bfv_plain_ringt": [vp, i, i, i, u64p, u64p, u64p],
+            "ora_bfv_scale_up": [vp, i, u64p, u64p],
         }.items():
             getattr(L, name).argtypes = args
             getattr(L, name).restype = None
@@ -208,6 +211,15 @@ class Oracle:
         npoly = ct.shape[0]
         o = np.empty((npoly, lvl, self.n), dtype=np.uint64)
         lib().ora_bfv_rescale(self.h, lvl, _p(ct), npoly, _p(o))
+        return o
+
+    def plain_ringt(self, op, lvl, ct, pt):
+        """op 0 add, 1 sub, 2 mul with a ring-t plaintext limb (CKKS: mod q_0, BFV: mod t)"""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        pt = np.ascontiguousarray(pt, dtype=np.uint64)
+        o = np.empty_like(ct)
+        fn = lib().ora_bfv_plain_ringt if self.t else lib().ora_ckks_plain_ringt
+        fn(self.h, op, lvl, ct.shape[0], _p(ct), _p(pt), _p(o))
         return o
 
     def bfv_mult_relin(self, lvl, a, b, rlk, klvl):

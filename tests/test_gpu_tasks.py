@@ -210,3 +210,90 @@ def test_bfv_tasks():
         assert np.array_equal(ys[i].data, o.bfv_rotate(lvl, xs[i], e, k, lvl))
         assert np.array_equal(c.bfv_decrypt(ys[i].data), np.concatenate([xm[i][h:], xm[i][:h]]))  # :551
     t.close()
+
+
+def test_ringt_plaintext_and_mac_tasks():
+    """ring-t plaintext operands and the ct-pt multiply-accumulate nodes (mega_ag_executors_gpu.cu:86-104,198-209,294-408):
+    GPU == oracle bit-exactly, and the decrypted message is the plain result."""
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, Plaintext
+    from oracle.client import mean_precision_bits
+    sc = 2.0 ** 34
+    # ---- CKKS ct (+,-,*) ring-t pt
+    for name, op, fn, out_scale in (("cap_ringt", 0, lambda x, y: x + y, sc), ("csp_ringt", 1, lambda x, y: x - y, sc),
+                                    ("cmp_ringt", 2, lambda x, y: x * y, sc * sc)):
+        g, P, o, c = _load("ckks_n4096_" + name)
+        n, lvl = P["n"], 2
+        xm, xs = _ckks_inputs(c, n, lvl, N_OP, 20 + op)
+        rng = np.random.default_rng(30 + op)
+        ym = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(N_OP)]
+        ys = [c.ckks_encode_ringt(m, sc) for m in ym]
+        t = _task("ckks_n4096_" + name)
+        zs = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP)]
+        t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Plaintext(y[None]) for y in ys])],
+              [Argument("out_z_list", zs)])
+        for i in range(N_OP):
+            assert np.array_equal(zs[i].data, o.plain_ringt(op, lvl, xs[i], ys[i])), name
+            re, im = mean_precision_bits(fn(xm[i], ym[i]), c.ckks_decrypt(zs[i].data, out_scale))
+            assert re >= 10 and im >= 10
+        t.close()
+    # ---- CKKS multiply-accumulate: z = sum_{i<5} c_i * p_i   (one mult + one 4-way cmpac_sum)
+    for name, ringt in (("cmpac", False), ("cmpac_ringt", True)):
+        g, P, o, c = _load("ckks_n4096_" + name)
+        n, lvl = P["n"], 2
+        cm, cs = _ckks_inputs(c, n, lvl, 5, 40)
+        rng = np.random.default_rng(41)
+        pm = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(5)]
+        ps = [c.ckks_encode_ringt(m, sc) if ringt else c.ckks_encode_ntt(m, lvl, sc) for m in pm]
+        t = _task("ckks_n4096_" + name)
+        z = [Ciphertext.empty(1, lvl, n)]
+        t.run([Argument("in_c_list", [Ciphertext(x) for x in cs]),
+               Argument("in_p_list", [Plaintext(p[None] if ringt else p) for p in ps])], [Argument("out_z_list", z)])
+        want = np.zeros((2, lvl + 1, n), dtype=np.uint64)
+        for i in range(5):
+            if ringt:
+                prod = o.plain_ringt(2, lvl, cs[i], ps[i])
+            else:
+                prod = np.stack([np.stack([o.vec("mul", j, cs[i][pl, j], ps[i][j]) for j in range(lvl + 1)]) for pl in range(2)])
+            want = np.stack([np.stack([o.vec("add", j, want[pl, j], prod[pl, j]) for j in range(lvl + 1)]) for pl in range(2)])
+        assert np.array_equal(z[0].data, want), name
+        re, im = mean_precision_bits(sum(cm[i] * pm[i] for i in range(5)), c.ckks_decrypt(z[0].data, sc * sc))
+        assert re >= 10 and im >= 10
+        t.close()
+    # ---- BFV ct (+,*) ring-t pt and MAC
+    for name, op in (("cap_ringt", 0), ("cmp_ringt", 2)):
+        g, P, o, c = _load("bfv_n4096_" + name)
+        n, lvl, tm = P["n"], 2, np.uint64(P["t"])
+        rng = np.random.default_rng(50 + op)
+        xm = [rng.integers(0, P["t"], size=n, dtype=np.uint64) for _ in range(N_OP)]
+        ym = [rng.integers(0, P["t"], size=n, dtype=np.uint64) for _ in range(N_OP)]
+        xs = [c.bfv_encrypt(m, lvl) for m in xm]
+        ys = [c.bfv_encode(m) for m in ym]
+        t = _task("bfv_n4096_" + name)
+        zs = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP)]
+        t.run([Argument("xs", [Ciphertext(x) for x in xs]), Argument("ys", [Plaintext(y[None]) for y in ys])], [Argument("zs", zs)])
+        for i in range(N_OP):
+            assert np.array_equal(zs[i].data, o.plain_ringt(op, lvl, xs[i], ys[i])), name
+            exp = (xm[i] + ym[i]) % tm if op == 0 else xm[i] * ym[i] % tm
+            assert np.array_equal(c.bfv_decrypt(zs[i].data), exp)
+        t.close()
+    g, P, o, c = _load("bfv_n4096_cmpac_ringt")
+    n, lvl, tm = P["n"], 2, np.uint64(P["t"])
+    rng = np.random.default_rng(60)
+    cmsg = [rng.integers(0, P["t"], size=n, dtype=np.uint64) for _ in range(3)]
+    pmsg = [rng.integers(0, P["t"], size=n, dtype=np.uint64) for _ in range(3)]
+    cs = [c.bfv_encrypt(m, lvl) for m in cmsg]
+    ps = [c.bfv_encode(m) for m in pmsg]
+    t = _task("bfv_n4096_cmpac_ringt")
+    z = [Ciphertext.empty(1, lvl, n)]
+    t.run([Argument("cs", [Ciphertext(x) for x in cs]), Argument("ps", [Plaintext(p[None]) for p in ps])], [Argument("zs", z)])
+    want = np.zeros((2, lvl + 1, n), dtype=np.uint64)
+    for i in range(3):
+        prod = o.plain_ringt(2, lvl, cs[i], ps[i])
+        want = np.stack([np.stack([o.vec("add", j, want[pl, j], prod[pl, j]) for j in range(lvl + 1)]) for pl in range(2)])
+    assert np.array_equal(z[0].data, want)
+    exp = np.zeros(n, dtype=np.uint64)
+    for i in range(3):
+        exp = (exp + cmsg[i] * pmsg[i]) % tm
+    assert np.array_equal(c.bfv_decrypt(z[0].data), exp)
+    t.close()

@@ -40,8 +40,8 @@ def test_missing_task_file_raises():
 
 def test_unsupported_operator_is_rejected_at_bind_time():
     from lattisense_amd.task import FheTaskGpu
-    with pytest.raises(RuntimeError, match="Unsupported operation type for GPU CKKS"):
-        FheTaskGpu(os.path.join(TASKS, "ckks_n4096_cap_ringt_unsupported"))
+    with pytest.raises(RuntimeError, match="Multiply with plaintext only supported for CKKS scheme"):
+        FheTaskGpu(os.path.join(TASKS, "bfv_n4096_cmp_unsupported"))
 
 
 def test_run_without_gpu_fails_loudly():

@@ -82,13 +82,42 @@ def main():
     emit("ckks_n4096_add_sub_neg_drop", [Argument("in_x_list", xs), Argument("in_y_list", ys)],
          [Argument("out_d_list", ds)])
 
-    # a graph this backend must REJECT at bind time (ring-t plaintext operand, scheduled for a later round)
-    set_fhe_param(ckks_param(4096, 5))
-    xs = [CkksCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
-    ys = [CkksPlaintextRingtNode(f"y_{i}") for i in range(N_OP)]
-    zs = [add(xs[i], ys[i], f"z_{i}") for i in range(N_OP)]
-    emit("ckks_n4096_cap_ringt_unsupported", [Argument("in_x_list", xs), Argument("in_y_list", ys)],
-         [Argument("out_z_list", zs)])
+    # ring-t plaintext operands (one coefficient-domain limb): ct + pt, ct - pt, ct * pt
+    for name, f in (("cap_ringt", add), ("csp_ringt", sub), ("cmp_ringt", mult)):
+        set_fhe_param(ckks_param(4096, 5))
+        xs = [CkksCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
+        ys = [CkksPlaintextRingtNode(f"y_{i}") for i in range(N_OP)]
+        zs = [f(xs[i], ys[i], f"z_{i}") for i in range(N_OP)]
+        emit("ckks_n4096_" + name, [Argument("in_x_list", xs), Argument("in_y_list", ys)], [Argument("out_z_list", zs)])
+
+    # ct-pt multiply-accumulate nodes (cmp_sum / cmpac_sum): m = 5 -> one 4-way MAC + one 1-way MAC with partial sum
+    for name, mk in (("cmpac", lambda i: CkksPlaintextNode(f"p_{i}", level=2)), ("cmpac_ringt", lambda i: CkksPlaintextRingtNode(f"p_{i}"))):
+        set_fhe_param(ckks_param(4096, 5))
+        cs = [CkksCiphertextNode(f"c_{i}", level=2) for i in range(5)]
+        ps = [mk(i) for i in range(5)]
+        z = ct_pt_mult_accumulate(cs, ps)
+        emit("ckks_n4096_" + name, [Argument("in_c_list", cs), Argument("in_p_list", ps)], [Argument("out_z_list", [z])])
+
+    # a graph this backend must REJECT at bind time, exactly as the reference does (mega_ag_executors_gpu.cu:212):
+    # BFV ciphertext x full plaintext
+    set_fhe_param(bfv_param(4096, 4))
+    xs = [BfvCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
+    ys = [BfvPlaintextNode(f"y_{i}", level=2) for i in range(N_OP)]
+    zs = [mult(xs[i], ys[i], f"z_{i}") for i in range(N_OP)]
+    emit("bfv_n4096_cmp_unsupported", [Argument("xs", xs), Argument("ys", ys)], [Argument("zs", zs)])
+
+    for name, f in (("cap_ringt", add), ("cmp_ringt", mult)):
+        set_fhe_param(bfv_param(4096, 4))
+        xs = [BfvCiphertextNode(f"x_{i}", level=2) for i in range(N_OP)]
+        ys = [BfvPlaintextRingtNode(f"y_{i}") for i in range(N_OP)]
+        zs = [f(xs[i], ys[i], f"z_{i}") for i in range(N_OP)]
+        emit("bfv_n4096_" + name, [Argument("xs", xs), Argument("ys", ys)], [Argument("zs", zs)])
+
+    set_fhe_param(bfv_param(4096, 4))
+    cs = [BfvCiphertextNode(f"c_{i}", level=2) for i in range(3)]
+    ps = [BfvPlaintextRingtNode(f"p_{i}") for i in range(3)]
+    z = ct_pt_mult_accumulate(cs, ps)
+    emit("bfv_n4096_cmpac_ringt", [Argument("cs", cs), Argument("ps", ps)], [Argument("zs", [z])])
 
     # CKKS ct+pt, ct*pt with full (NTT-domain) plaintexts
     set_fhe_param(ckks_param(4096, 5))
