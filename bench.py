@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep", "task_ckks", "task_bfv"])
+    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep", "deep17", "task_ckks", "task_bfv"])
     ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU (0 = workload default)")
     ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
     ap.add_argument("--ntt-chunk-mib", type=int, default=-1, help="Infinity-Cache chunk of two-pass NTTs (-1 = default)")
@@ -69,6 +69,11 @@ def workload_config(name):
         return dict(algo=1, n=65536, q=P["q"], p=P["p"], t=0, level=24, batch=64,
                     label="CKKS N=2^16 25Q+5P deep-chain HMult+relin+rescale", unit="ciphertexts/s",
                     metric="ckks_deep_hmult_throughput")
+    if name == "deep17":
+        P = params.ckks_n17_chain()
+        return dict(algo=1, n=1 << 17, q=P["q"], p=P["p"], t=0, level=24, batch=32,
+                    label="CKKS N=2^17 25Q+5P (generated chain) HMult+relin+rescale", unit="ciphertexts/s",
+                    metric="ckks_n17_deep_hmult_throughput")
     P = params.BFV_DEFAULT[16384]
     return dict(algo=0, n=16384, q=P["q"], p=P["p"], t=P["t"], level=3, batch=1024,
                 label="BFV N=2^14 4 primes batch 1024 ct NTT+INTT", unit="GB/s", metric="ntt_intt_algorithmic_bandwidth")
@@ -191,15 +196,15 @@ def main():
         key = ctx.adopt_key(key_t.data_ptr(), lvl)
 
     a = uniform((batch, 2), qs)
-    b = uniform((batch, 2), qs) if args.workload in ("ckks_hmult", "bfv_hmult", "deep") else None
-    if args.workload in ("ckks_hmult", "deep"):
+    b = uniform((batch, 2), qs) if args.workload in ("ckks_hmult", "bfv_hmult", "deep", "deep17") else None
+    if args.workload in ("ckks_hmult", "deep", "deep17"):
         out = torch.empty(batch, 2, lvl, n, dtype=torch.int64, device=dev)
     else:
         out = torch.empty(batch, 2, L, n, dtype=torch.int64, device=dev)
     g_rot = pow(5, 1, 2 * n)
 
     def step():
-        if args.workload in ("ckks_hmult", "deep"):
+        if args.workload in ("ckks_hmult", "deep", "deep17"):
             ctx.ckks_mult_relin_rescale(lvl, Buf(a), Buf(b), key, batch, out=Buf(out))
         elif args.workload == "bfv_hmult":
             ctx.bfv_mult_relin(lvl, Buf(a), Buf(b), key, batch, out=Buf(out))
@@ -307,7 +312,7 @@ def cpu_baseline(workload, cfg):
 
     def work():
         for _ in range(per_thread):
-            if workload in ("ckks_hmult", "deep"):
+            if workload in ("ckks_hmult", "deep", "deep17"):
                 o.ckks_mult_relin_rescale(lvl, a, b, key, lvl)
             elif workload == "bfv_hmult":
                 o.bfv_mult_relin(lvl, a, b, key, lvl)

@@ -17,6 +17,8 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <thread>
 
 #include "lsa_internal.h"
@@ -68,14 +70,69 @@ void lsa_free_ciphertext(CCiphertext* ct) {
 namespace {
 
 // ------------------------------------------------------------------------------------------------ device data
+// Buffers (device or pinned host) recycled across levels and run() calls: hipMalloc/hipFree and pinned allocation cost
+// milliseconds and synchronise the device, so a task keeps what it allocated.  All work of a run is on one in-order
+// stream, so handing a released device buffer to a later kernel is ordered after its earlier readers.
+struct BufPool {
+    bool pinned;
+    std::mutex mu;
+    std::multimap<size_t, u64*> free_list;
+    explicit BufPool(bool pinned_) : pinned(pinned_) {}
+    u64* take(size_t words) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_list.find(words);
+            if (it != free_list.end()) {
+                u64* p = it->second;
+                free_list.erase(it);
+                return p;
+            }
+        }
+        u64* p = nullptr;
+        if (pinned) LSA_HIP(hipHostMalloc((void**)&p, words * sizeof(u64), hipHostMallocDefault));
+        else LSA_HIP(hipMalloc((void**)&p, words * sizeof(u64)));
+        return p;
+    }
+    void give(size_t words, u64* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        free_list.emplace(words, p);
+    }
+    ~BufPool() {
+        for (auto& kv : free_list) {
+            if (pinned) (void)hipHostFree(kv.second);
+            else (void)hipFree(kv.second);
+        }
+    }
+};
+
 struct Slab {
     u64* ptr = nullptr;
     size_t words = 0;
-    explicit Slab(size_t w) : words(w) { LSA_HIP(hipMalloc((void**)&ptr, w * sizeof(u64))); }
-    ~Slab() { (void)hipFree(ptr); }
+    BufPool* pool;
+    Slab(BufPool& p, size_t w) : words(w), pool(&p) { ptr = p.take(w); }
+    ~Slab() { pool->give(words, ptr); }
     Slab(const Slab&) = delete;
     Slab& operator=(const Slab&) = delete;
 };
+
+// static-chunk parallel loop on a few host threads (memcpy-bound staging work)
+template <typename F> void parallel_for(size_t n, F&& fn) {
+    if (n == 0) return;
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({n, (size_t)std::max(1, std::min(16, hw > 0 ? hw : 1) - 2), 14}));
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) return;
+            fn(i);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+}
 
 struct DevDatum {  // a ciphertext or plaintext living in (a slice of) a slab: [polys][level+1][N]
     std::shared_ptr<Slab> slab;
@@ -178,6 +235,8 @@ void bind_gpu_executor(ComputeNode& node, Algo algorithm) {
 }
 
 struct fhe_task_handle_st {
+    BufPool dev_pool{false}, pin_pool{true};   // declared first: destroyed last (slabs below give their buffers back)
+    std::shared_ptr<Slab> dslab(size_t words) { return std::make_shared<Slab>(dev_pool, words); }
     TaskGraph g;
     std::vector<std::vector<ComputeNode*>> levels;
     std::map<int, std::unique_ptr<Context>> contexts;
@@ -309,13 +368,18 @@ struct fhe_task_handle_st {
         if (total == 0) return;
         // 2. gather limbs into the pinned staging slab, one H2D copy per group
         u64* host = stage.ensure(total);
+        struct Job {
+            u64* dst;
+            const u64* src;
+        };
+        std::vector<Job> jobs;   // one limb each, gathered by a few threads (single-threaded this was ~55 % of LOAD)
         for (auto& kv : groups)
             for (auto& it : kv.second) {
                 u64* dst = host + it.off;
                 for (int p = 0; p < it.polys; p++) {
                     const CPolynomial& poly = it.ct ? it.ct->polys[p] : it.pt->poly;
                     for (int j = 0; j <= it.level; j++) {
-                        memcpy(dst, poly.components[j].data, sizeof(u64) * N);
+                        jobs.push_back({dst, poly.components[j].data});
                         dst += N;
                     }
                 }
@@ -325,14 +389,15 @@ struct fhe_task_handle_st {
             for (int d = 0; d < k.beta; d++)
                 for (int h = 0; h < 2; h++)
                     for (int j = 0; j < k.comp; j++) {
-                        memcpy(dst, k.ksk->public_keys[d].polys[h].components[j].data, sizeof(u64) * N);
+                        jobs.push_back({dst, k.ksk->public_keys[d].polys[h].components[j].data});
                         dst += N;
                     }
         }
+        parallel_for(jobs.size(), [&](size_t i) { memcpy(jobs[i].dst, jobs[i].src, sizeof(u64) * N); });
         for (auto& kv : groups) {
             auto& items = kv.second;
             const size_t per = (size_t)items[0].polys * (items[0].level + 1) * N;
-            auto slab = std::make_shared<Slab>(per * items.size());
+            auto slab = dslab(per * items.size());
             LSA_HIP(hipMemcpyAsync(slab->ptr, host + items[0].off, per * items.size() * sizeof(u64), hipMemcpyHostToDevice, s));
             for (size_t i = 0; i < items.size(); i++) {
                 auto d = std::make_shared<DevDatum>();
@@ -347,7 +412,7 @@ struct fhe_task_handle_st {
         for (auto& k : keys) {
             const size_t words = (size_t)k.beta * 2 * k.comp * N;
             auto dk = std::make_shared<DevKey>();
-            dk->slab = std::make_shared<Slab>(words);
+            dk->slab = dslab(words);
             LSA_HIP(hipMemcpyAsync(dk->slab->ptr, host + k.off, words * sizeof(u64), hipMemcpyHostToDevice, s));
             dk->key.data = dk->slab->ptr;
             dk->key.level = k.level;
@@ -374,7 +439,10 @@ struct fhe_task_handle_st {
             items.push_back({d, total});
             total += (size_t)d->polys * (d->level + 1) * N;
         }
-        u64* host = stage.ensure(total);
+        // results land in ONE pooled pinned slab; the C structs handed to the caller's import executor only index it
+        // (no malloc per limb, no second host copy).  The slab returns to the pool when the last struct is released.
+        auto hslab = std::make_shared<Slab>(pin_pool, total);
+        u64* host = hslab->ptr;
         // merge runs that are contiguous on the device into single copies
         for (size_t i = 0; i < items.size();) {
             size_t j = i, words = 0;
@@ -389,17 +457,24 @@ struct fhe_task_handle_st {
         for (size_t i = 0; i < nodes.size(); i++) {
             const DatumP& d = items[i].first;
             auto* ct = (CCiphertext*)malloc(sizeof(CCiphertext));
-            lsa_alloc_ciphertext(ct, d->polys - 1, d->level, c.n);
-            std::shared_ptr<CCiphertext> sp(ct, [](CCiphertext* p) {
-                lsa_free_ciphertext(p);
-                free(p);
-            });
-            const u64* src = host + items[i].second;
-            for (int p = 0; p < d->polys; p++)
+            ct->level = d->level;
+            ct->degree = d->polys - 1;
+            ct->polys = (CPolynomial*)malloc(sizeof(CPolynomial) * (size_t)d->polys);
+            u64* src = host + items[i].second;
+            for (int p = 0; p < d->polys; p++) {
+                ct->polys[p].n_component = d->level + 1;
+                ct->polys[p].components = (CComponent*)malloc(sizeof(CComponent) * (size_t)(d->level + 1));
                 for (int j = 0; j <= d->level; j++) {
-                    memcpy(ct->polys[p].components[j].data, src, sizeof(u64) * N);
+                    ct->polys[p].components[j].n = c.n;
+                    ct->polys[p].components[j].data = src;
                     src += N;
                 }
+            }
+            std::shared_ptr<CCiphertext> sp(ct, [hslab](CCiphertext* q) {
+                for (int p = 0; p <= q->degree; p++) free(q->polys[p].components);
+                free(q->polys);
+                free(q);
+            });
             avail[nodes[i]->output_nodes[0]->index] = sp;
         }
     }
@@ -424,7 +499,7 @@ struct fhe_task_handle_st {
             o.stride = st;
             return o;
         }
-        o.keep = std::make_shared<Slab>(words * d.size());
+        o.keep = dslab(words * d.size());
         for (size_t i = 0; i < d.size(); i++)
             LSA_HIP(hipMemcpyAsync(o.keep->ptr + words * i, d[i]->ptr, words * sizeof(u64), hipMemcpyDeviceToDevice, s));
         o.ptr = o.keep->ptr;
@@ -461,7 +536,7 @@ struct fhe_task_handle_st {
         if (op == OperationType::MULTIPLY && !(n0->input_nodes.size() == 2 && is_plain_node(n0->input_nodes[1]))) out_polys = 3;
         if (op == OperationType::RELINEARIZE) out_polys = 2;
         const size_t w_out = (size_t)out_polys * (out_lvl + 1) * N;
-        auto out_slab = std::make_shared<Slab>(w_out * m);
+        auto out_slab = dslab(w_out * m);
         u64* out = out_slab->ptr;
         const long long so = (long long)w_out;
         Operand a = gather(c, s, nodes, 0, avail, w_in);
@@ -476,7 +551,7 @@ struct fhe_task_handle_st {
         auto plain_operand = [&](int pos, int ringt_mode, bool to_ntt) -> Operand {
             if (!is_ringt_node(n0->input_nodes[pos])) return gather(c, s, nodes, pos, avail, (size_t)L * N);
             Operand raw = gather(c, s, nodes, pos, avail, (size_t)N);
-            Operand o{nullptr, (long long)L * N, std::make_shared<Slab>((size_t)m * L * N)};
+            Operand o{nullptr, (long long)L * N, dslab((size_t)m * L * N)};
             pending_free.push_back(o.keep);
             launch_lift_ringt(c, ringt_mode, lvl, raw.ptr, raw.stride, o.keep->ptr, o.stride, m, s);
             if (to_ntt) launch_ntt(c, o.keep->ptr, o.keep->ptr, m, o.stride, L, rmL, false, s);
@@ -484,7 +559,7 @@ struct fhe_task_handle_st {
             return o;
         };
         auto temp = [&](size_t words) {
-            auto sl = std::make_shared<Slab>(words);
+            auto sl = dslab(words);
             pending_free.push_back(sl);
             return sl->ptr;
         };
@@ -716,14 +791,31 @@ struct fhe_task_handle_st {
                     buckets[sg].push_back(n);
                 }
             }
+            const bool trace = getenv("LSA_TASK_TRACE") != nullptr;
+            auto tick = [&]() { return std::chrono::steady_clock::now(); };
+            auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+                return std::chrono::duration<double, std::milli>(tick() - t0).count();
+            };
+            auto t0 = tick();
             if (!loads.empty()) run_loads(c, s, loads, avail);
+            const double t_load = ms_since(t0);
+            t0 = tick();
             for (auto& sg : bucket_order) {
                 run_gpu_bucket(c, s, buckets[sg], avail);
                 last_gpu_nodes += (int)buckets[sg].size();
                 last_gpu_batches++;
             }
+            if (trace && !bucket_order.empty()) LSA_HIP(hipStreamSynchronize(s));
+            const double t_gpu = ms_since(t0);
+            t0 = tick();
             if (!stores.empty()) run_stores(c, s, stores, avail);
+            const double t_store = ms_since(t0);
+            t0 = tick();
             run_cpu_nodes(cpu, avail, out_handles);
+            const double t_cpu = ms_since(t0);
+            if (trace)
+                fprintf(stderr, "[lsa task] level: %zu nodes  load %.2f ms  gpu %.2f ms  store %.2f ms  cpu %.2f ms\n",
+                        level.size(), t_load, t_gpu, t_store, t_cpu);
             for (ComputeNode* n : level)
                 for (auto* in : n->input_nodes)
                     if (--refs[in->index] <= 0 && !in->is_input && !in->is_output) avail.erase(in->index);

@@ -127,3 +127,27 @@ def test_deep_chain_keyswitch_bootstrap_primes():
     out = ctx.ckks_mult_relin_rescale(lvl, ctx.upload(A), ctx.upload(Bc), k, batch)
     want = np.stack([o.ckks_mult_relin_rescale(lvl, A[i], Bc[i], key, klvl) for i in range(batch)])
     assert np.array_equal(ctx.download(out, want.shape), want)
+
+
+def test_n17_deep_chain_hmult_bit_exact():
+    """BASELINE configs[4] shape at full size: N=2^17, 25 Q-limbs + 5 special primes (generated chain, the reference has
+    none for this degree), HMult+relin+rescale of one ciphertext pair against the oracle; also exercises the 8+9 stage
+    pass split and limb mixes of both butterfly engines."""
+    need_gpu()
+    from lattisense_amd.device import DeviceContext, ALGO_CKKS
+    from oracle.pyoracle import Oracle
+    C = params.ckks_n17_chain()
+    n, q, p = C["n"], C["q"], C["p"]
+    lvl = klvl = len(q) - 1
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    o = Oracle(n, q, p, 0)
+    rng = np.random.default_rng(17)
+    A, Bc = rand_ct(rng, q, 2, n, 1), rand_ct(rng, q, 2, n, 1)
+    beta = (lvl + 1 + len(p) - 1) // len(p)
+    key = np.empty((beta, 2, lvl + 1 + len(p), n), dtype=np.uint64)
+    for j, m in enumerate(q + p):
+        key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+    k = ctx.upload_key(key, klvl)
+    out = ctx.ckks_mult_relin_rescale(lvl, ctx.upload(A), ctx.upload(Bc), k, 1)
+    want = o.ckks_mult_relin_rescale(lvl, A[0], Bc[0], key, klvl)[None]
+    assert np.array_equal(ctx.download(out, want.shape), want)
