@@ -78,3 +78,32 @@ def test_bfv_rotate_and_rescale():
     got = ctx.download(rs, want.shape)
     assert np.array_equal(got, want)
     assert np.array_equal(c.bfv_decrypt(got[0]), x)
+
+
+@pytest.mark.parametrize("tag", ["default_n8192_k1", "default_n16384_k2", "default_n32768_k3"])
+def test_bfv_every_level_mult_relin(tag):
+    """BFV parameter sets of the reference (fixture.hpp:63-85 + frontend/parameter.json) incl. the 12-limb chain whose
+    Q -> QMul extension has 12 source limbs; every level, ring degree shrunk to 1024 for the oracle."""
+    need_gpu()
+    from lattisense_amd.device import DeviceContext, ALGO_BFV
+    from oracle.pyoracle import Oracle
+    from tests.gpu_util import rand_ct
+    P = params.BFV_DEFAULT[{"default_n8192_k1": 8192, "default_n16384_k2": 16384, "default_n32768_k3": 32768}[tag]]
+    q, p, t = P["q"], P["p"], P["t"]
+    n = 1024
+    ctx = DeviceContext(ALGO_BFV, n, q, p, t)
+    o = Oracle(n, q, p, t)
+    assert ctx.moduli == o.mod
+    rng = np.random.default_rng(len(q))
+    klvl = len(q) - 1
+    beta = (klvl + 1 + len(p) - 1) // len(p)
+    key = np.empty((beta, 2, klvl + 1 + len(p), n), dtype=np.uint64)
+    for j, m in enumerate(q + p):
+        key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+    k = ctx.upload_key(key, klvl)
+    levels = range(0, len(q)) if len(q) <= 6 else [0, 1, 5, 8, 11]
+    for lvl in levels:
+        A, Bc = rand_ct(rng, q[: lvl + 1], 2, n, 2), rand_ct(rng, q[: lvl + 1], 2, n, 2)
+        out = ctx.bfv_mult_relin(lvl, ctx.upload(A), ctx.upload(Bc), k, 2)
+        want = np.stack([o.bfv_mult_relin(lvl, A[i], Bc[i], key, klvl) for i in range(2)])
+        assert np.array_equal(ctx.download(out, want.shape), want), (tag, lvl)

@@ -151,3 +151,85 @@ def test_n17_deep_chain_hmult_bit_exact():
     out = ctx.ckks_mult_relin_rescale(lvl, ctx.upload(A), ctx.upload(Bc), k, 1)
     want = o.ckks_mult_relin_rescale(lvl, A[0], Bc[0], key, klvl)[None]
     assert np.array_equal(ctx.download(out, want.shape), want)
+
+
+# parameter sets of the reference's GPU tests (unittests/fixture.hpp:87-118, test_gpu_ckks.py:39-56): default chains and
+# the custom N=8192 chain with ONE special prime (digit width 1: every digit is a single limb)
+_CUSTOM_8192 = dict(q=[0x1FFFEC001, 0x3FFF4001, 0x3FFE8001, 0x40020001, 0x40038001, 0x3FFC0001], p=[0x800004001])
+
+
+@pytest.mark.parametrize("tag", ["default_n8192", "custom_n8192_k1", "default_n16384_k2"])
+def test_every_level_mult_relin_rescale_and_square(tag):
+    """The reference generates one task per level (conftest.py:24-69); here every level >= 1 of each parameter set runs
+    HMult+relin+rescale and a same-operand multiply (executors_gpu.cu:178-186) against the oracle, with ring degree
+    shrunk to 1024 so the oracle stays fast (the prime chains, digit structure and level logic are the real ones)."""
+    need_gpu()
+    from lattisense_amd.device import DeviceContext, ALGO_CKKS
+    from oracle.pyoracle import Oracle
+    if tag == "default_n8192":
+        P = params.CKKS_DEFAULT[8192]
+        q, p = P["q"], P["p"]
+    elif tag == "custom_n8192_k1":
+        q, p = _CUSTOM_8192["q"], _CUSTOM_8192["p"]
+    else:
+        P = params.CKKS_DEFAULT[16384]
+        q, p = P["q"], P["p"]
+    n = 1024
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    o = Oracle(n, q, p, 0)
+    rng = np.random.default_rng(len(q))
+    klvl = len(q) - 1
+    beta = (klvl + 1 + len(p) - 1) // len(p)
+    key = np.empty((beta, 2, klvl + 1 + len(p), n), dtype=np.uint64)
+    for j, m in enumerate(q + p):
+        key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+    k = ctx.upload_key(key, klvl)     # one key at the top level serves every lower level
+    batch = 2
+    for lvl in range(1, len(q)):
+        A, Bc = rand_ct(rng, q[: lvl + 1], 2, n, batch), rand_ct(rng, q[: lvl + 1], 2, n, batch)
+        da, db = ctx.upload(A), ctx.upload(Bc)
+        out = ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch)
+        want = np.stack([o.ckks_mult_relin_rescale(lvl, A[i], Bc[i], key, klvl) for i in range(batch)])
+        assert np.array_equal(ctx.download(out, want.shape), want), (tag, lvl)
+        sq = ctx.ckks_mult(lvl, da, da, batch)
+        want_sq = np.stack([o.ckks_mult(lvl, A[i], A[i]) for i in range(batch)])
+        assert np.array_equal(ctx.download(sq, want_sq.shape), want_sq), (tag, lvl)
+        # unfused tails must give the same residues as the fused default
+        from lattisense_amd._native import check, lib
+        check(lib().lsa_set_fuse_tails(ctx.h, 0))
+        out2 = ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch)
+        assert np.array_equal(ctx.download(out2, want.shape), want), (tag, lvl, "unfused")
+        check(lib().lsa_set_fuse_tails(ctx.h, 1))
+    # level 0 ciphertexts still multiply and relinearise (no rescale possible)
+    A, Bc = rand_ct(rng, q[:1], 2, n, batch), rand_ct(rng, q[:1], 2, n, batch)
+    d3 = ctx.ckks_mult(0, ctx.upload(A), ctx.upload(Bc), batch)
+    r2 = ctx.ckks_relin(0, d3, k, batch)
+    want = np.stack([o.ckks_relin(0, o.ckks_mult(0, A[i], Bc[i]), key, klvl) for i in range(batch)])
+    assert np.array_equal(ctx.download(r2, want.shape), want)
+
+
+def test_engine_and_stream_variants_agree():
+    """integer vs FP64 butterfly engine, single vs dual stream: identical outputs on the headline operator"""
+    need_gpu()
+    from lattisense_amd._native import check, lib
+    from lattisense_amd.device import DeviceContext, ALGO_CKKS
+    P = params.CKKS_DEFAULT[65536]
+    n, q, p = 8192, P["q"][:7], P["p"]
+    lvl = 6
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    rng = np.random.default_rng(77)
+    batch = 6
+    A, Bc = rand_ct(rng, q, 2, n, batch), rand_ct(rng, q, 2, n, batch)
+    beta = (lvl + 1 + len(p) - 1) // len(p)
+    key = np.empty((beta, 2, lvl + 1 + len(p), n), dtype=np.uint64)
+    for j, m in enumerate(q + p):
+        key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+    k = ctx.upload_key(key, lvl)
+    da, db = ctx.upload(A), ctx.upload(Bc)
+    ref = ctx.download(ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch), (batch, 2, lvl, n))
+    for fp64, dual, tile in [(0, 0, 0), (1, 1, 2), (0, 1, 4), (1, 0, 1)]:
+        ctx.set_fp64_ntt(fp64)
+        check(lib().lsa_set_dual_stream(ctx.h, dual))
+        ctx.set_tile_batch(tile)
+        got = ctx.download(ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch), (batch, 2, lvl, n))
+        assert np.array_equal(got, ref), (fp64, dual, tile)
