@@ -262,6 +262,20 @@ def main():
                     "avg_launch_us": ntt["avg_launch_us"], "launches_per_step": ntt["launches_per_step"],
                     "sampling": "HIP event pair around every %d-th launch, on the launch stream" % args.prof_stride}
 
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed
+    # rocprofv3 --pmc passes of this same command (tools/profile.sh -> profiles/), matched on workload and batch.
+    if roofline:
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_k_ntt_pass.json")))
+            pmc = json.load(open(cands[-1])) if cands else None
+            if pmc and pmc["workload"] == args.workload and pmc["batch"] == batch:
+                roofline["traffic"] = pmc["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = os.path.relpath(cands[-1], ROOT)
+                roofline["algorithmic_bytes_per_launch"] = ntt["achieved_GBps"] * 1e9 * ntt["avg_launch_us"] * 1e-6
+        except Exception:
+            pass
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, cfg)
