@@ -27,7 +27,11 @@ Context::Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_
     LSA_REQUIRE(nmod < LSA_ROW_SKIP, "too many moduli");
     T.build(n, mods);
     logn = T.logn;
-    plan = make_ntt_plan(logn, 12);
+#ifndef LSA_NTT_TAU
+#define LSA_NTT_TAU 12   // log2 of the LDS tile (points per workgroup pass)
+#endif
+    plan = make_ntt_plan(logn, LSA_NTT_TAU);
+    LSA_REQUIRE(plan.npass == 1 || plan.pass[1].mu <= plan.pass[1].tau, "ring degree too large for the NTT tile size");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

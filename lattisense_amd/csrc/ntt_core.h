@@ -141,6 +141,10 @@ LSA_HD u64 d_to_bits(double d) {
     return b;
 #endif
 }
+// exact u64 <-> double for integers below 2^52 through the 2^52 offset trick (2 instructions each way instead of the
+// generic 64-bit conversions)
+LSA_HD double u52_to_double(u64 v) { return d_from_bits(v | 0x4330000000000000ull) - 4503599627370496.0; }
+LSA_HD u64 double_to_u52(double r) { return d_to_bits(r + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull; }
 // v*w mod q as an integer-valued double in (-1.1q, 1.1q); |v| < 2^51, 0 <= w < q < 2^47
 LSA_HD double fp_modmul(double v, double w, double q, double qinv) {
     const double h = v * w;
@@ -178,8 +182,8 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
             v1 = sub_mod(reduce_u64(add_mod(v1, h, ml.q), mi), hq, mi.q);
         }
         if (bc.fp) {  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact as doubles
-            v0 = d_to_bits((double)v0);
-            v1 = d_to_bits((double)v1);
+            v0 = d_to_bits(u52_to_double(v0));
+            v1 = d_to_bits(u52_to_double(v1));
         }
         lds[lds_addr(l)] = v0;
         lds[lds_addr(l + 1)] = v1;
@@ -216,8 +220,8 @@ LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int ti
         if (i < half) {
             u64 v0 = stage[2 * p], v1 = stage[2 * p + 1];
             if (bc.fp) {
-                v0 = d_to_bits((double)v0);
-                v1 = d_to_bits((double)v1);
+                v0 = d_to_bits(u52_to_double(v0));
+                v1 = d_to_bits(u52_to_double(v1));
             }
             lds[lds_addr(2 * i)] = v0;
             lds[lds_addr(2 * i + 1)] = v1;
@@ -237,12 +241,10 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         u64 v0 = lds[lds_addr(l)], v1 = lds[lds_addr(l + 1)];
         if (bc.fp) {  // always canonical on store: the next pass reloads exact small integers
             double r0 = fp_reduce(d_from_bits(v0), qd, qinvd), r1 = fp_reduce(d_from_bits(v1), qd, qinvd);
-            if (r0 < 0) r0 += qd;
+            if (r0 < 0) r0 += qd;   // |r| <= q/2 (+ rounding slack): one conditional add lands in [0, q)
             if (r1 < 0) r1 += qd;
-            v0 = (u64)r0;
-            v1 = (u64)r1;
-            v0 = csub(v0, q);
-            v1 = csub(v1, q);
+            v0 = double_to_u52(r0);
+            v1 = double_to_u52(r1);
         } else if (a.final_reduce) {
             v0 = csub(csub(v0, 2 * q), q);
             v1 = csub(csub(v1, 2 * q), q);
@@ -275,7 +277,9 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
 }
 
 // One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass — integer (Montgomery) engine.
-template <int RHO>
+// LIN: the padded LDS addresses of a group's 2^RHO elements are an arithmetic progression (beta0 == 0 or >= 4), so one
+// add per element replaces the shift/add padding arithmetic.
+template <int RHO, bool LIN>
 LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const ModDev md = a.mods[bc.mod];
@@ -283,11 +287,14 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
     const u64* tw = a.tw + ((long long)bc.mod << a.logn);
     const int beta0 = a.lambda + a.mu - sig0 - RHO;  // lowest active bit of this sub-pass in l
     const int ngroups = 1 << (a.tau - RHO);
+    const bool scale_here = a.inverse && a.apply_scale && a.s_lo + sig0 == 0;
+    const u64 sc0 = scale_here ? a.scale[2 * bc.mod] : 0, sc1 = scale_here ? a.scale[2 * bc.mod + 1] : 0;
     for (int gid = tid; gid < ngroups; gid += LSA_NTT_THREADS) {
         int lbase = ((gid >> beta0) << (beta0 + RHO)) | (gid & ((1 << beta0) - 1));
+        const int ad0 = lds_addr(lbase), adst = !LIN ? 0 : beta0 ? (1 << beta0) + (1 << (beta0 - 4)) : 1;
         u64 v[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) v[e] = lds[lds_addr(lbase + (e << beta0))];
+        for (int e = 0; e < E; e++) v[e] = lds[LIN ? ad0 + e * adst : lds_addr(lbase + (e << beta0))];
         // G = H * 2^sig0 + r_high ; r = (l >> lambda) & (2^mu - 1)
         int r = (lbase >> a.lambda) & ((1 << a.mu) - 1);
         int H = ntt_hi_index(a, bc.tile, lbase);
@@ -315,38 +322,46 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
                 const int half = E >> (j + 1);
                 const int s = a.s_lo + sig0 + j;
                 const u64* twj = tw + (1 << s) + ((long long)G << j);
-                const bool last = a.apply_scale && s == 0;
+                if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
+#pragma unroll
+                    for (int e = 0; e < half; e++) {
+                        u64 U = v[e], V = v[e + half];   // both in [0,2q)
+                        v[e] = mont_mul_lazy(U + V, sc0, q, qinv);
+                        v[e + half] = mont_mul_lazy(U + q2 - V, sc1, q, qinv);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
-                        u64 w = last ? a.scale[2 * bc.mod + 1] : twj[e >> (RHO - j)];
                         u64 U = v[e], V = v[e + half];   // both in [0,2q)
-                        u64 S = U + V;                    // [0,4q)
-                        u64 D = U + q2 - V;               // (0,4q)
-                        v[e] = last ? mont_mul_lazy(S, a.scale[2 * bc.mod], q, qinv) : csub(S, q2);
-                        v[e + half] = mont_mul_lazy(D, w, q, qinv);
+                        v[e] = csub(U + V, q2);
+                        v[e + half] = mont_mul_lazy(U + q2 - V, twj[e >> (RHO - j)], q, qinv);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int e = 0; e < E; e++) lds[lds_addr(lbase + (e << beta0))] = v[e];
+        for (int e = 0; e < E; e++) lds[LIN ? ad0 + e * adst : lds_addr(lbase + (e << beta0))] = v[e];
     }
 }
 
 // The same sub-pass on the FP64 engine: LDS holds integer-valued doubles.
-template <int RHO>
+template <int RHO, bool LIN>
 LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const double q = (double)a.mods[bc.mod].q, qinv = 1.0 / q;
     const double* tw = a.twd + ((long long)bc.mod << a.logn);
     const int beta0 = a.lambda + a.mu - sig0 - RHO;
     const int ngroups = 1 << (a.tau - RHO);
+    const bool scale_here = a.inverse && a.apply_scale && a.s_lo + sig0 == 0;
+    const double sc0 = scale_here ? a.scaled[2 * bc.mod] : 0.0, sc1 = scale_here ? a.scaled[2 * bc.mod + 1] : 0.0;
     for (int gid = tid; gid < ngroups; gid += LSA_NTT_THREADS) {
         int lbase = ((gid >> beta0) << (beta0 + RHO)) | (gid & ((1 << beta0) - 1));
+        const int ad0 = lds_addr(lbase), adst = !LIN ? 0 : beta0 ? (1 << beta0) + (1 << (beta0 - 4)) : 1;
         double v[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) v[e] = d_from_bits(lds[lds_addr(lbase + (e << beta0))]);
+        for (int e = 0; e < E; e++) v[e] = d_from_bits(lds[LIN ? ad0 + e * adst : lds_addr(lbase + (e << beta0))]);
         int r = (lbase >> a.lambda) & ((1 << a.mu) - 1);
         int H = ntt_hi_index(a, bc.tile, lbase);
         int G = (H << sig0) + (r >> (a.mu - sig0));
@@ -376,15 +391,21 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
                 const int half = E >> (j + 1);
                 const int s = a.s_lo + sig0 + j;
                 const double* twj = tw + (1 << s) + ((long long)G << j);
-                const bool last = a.apply_scale && s == 0;
+                if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
+#pragma unroll
+                    for (int e = 0; e < half; e++) {
+                        const double U = v[e], V = v[e + half];
+                        v[e] = fp_modmul(U + V, sc0, q, qinv);
+                        v[e + half] = fp_modmul(U - V, sc1, q, qinv);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
-                        const double w = last ? a.scaled[2 * bc.mod + 1] : twj[e >> (RHO - j)];
                         const double U = v[e], V = v[e + half];
-                        const double S = U + V, D = U - V;   // sums at most double per stage: < 16 * 1.1q inside a sub-pass
-                        v[e] = last ? fp_modmul(S, a.scaled[2 * bc.mod], q, qinv) : S;
-                        v[e + half] = fp_modmul(D, w, q, qinv);
+                        v[e] = U + V;   // sums at most double per stage: < 16 * 1.1q inside a sub-pass
+                        v[e + half] = fp_modmul(U - V, twj[e >> (RHO - j)], q, qinv);
                     }
                 }
             }
@@ -392,7 +413,7 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
             for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], q, qinv);  // back to |.| <= q/2+1 before the next sub-pass
         }
 #pragma unroll
-        for (int e = 0; e < E; e++) lds[lds_addr(lbase + (e << beta0))] = d_to_bits(v[e]);
+        for (int e = 0; e < E; e++) lds[LIN ? ad0 + e * adst : lds_addr(lbase + (e << beta0))] = d_to_bits(v[e]);
     }
 }
 
@@ -404,16 +425,17 @@ LSA_HD int ntt_plan(int mu, int* rho /*[4]*/) {
     return n;
 }
 
-LSA_HD void ntt_phase_sub_dyn(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
+template <bool LIN>
+LSA_HD void ntt_phase_sub_sel(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
     if (bc.fp) {
         switch (rho) {
-            case 1: ntt_phase_sub_fp<1>(a, bc, tid, lds, sig0); break;
-            case 2: ntt_phase_sub_fp<2>(a, bc, tid, lds, sig0); break;
+            case 1: ntt_phase_sub_fp<1, LIN>(a, bc, tid, lds, sig0); break;
+            case 2: ntt_phase_sub_fp<2, LIN>(a, bc, tid, lds, sig0); break;
 #if LSA_NTT_MAX_RHO >= 4
-            case 3: ntt_phase_sub_fp<3>(a, bc, tid, lds, sig0); break;
-            default: ntt_phase_sub_fp<4>(a, bc, tid, lds, sig0); break;
+            case 3: ntt_phase_sub_fp<3, LIN>(a, bc, tid, lds, sig0); break;
+            default: ntt_phase_sub_fp<4, LIN>(a, bc, tid, lds, sig0); break;
 #elif LSA_NTT_MAX_RHO == 3
-            default: ntt_phase_sub_fp<3>(a, bc, tid, lds, sig0); break;
+            default: ntt_phase_sub_fp<3, LIN>(a, bc, tid, lds, sig0); break;
 #else
             default: break;
 #endif
@@ -421,15 +443,23 @@ LSA_HD void ntt_phase_sub_dyn(const NttPassArgs& a, const NttBlockCtx& bc, int t
         return;
     }
     switch (rho) {
-        case 1: ntt_phase_sub<1>(a, bc, tid, lds, sig0); break;
-        case 2: ntt_phase_sub<2>(a, bc, tid, lds, sig0); break;
+        case 1: ntt_phase_sub<1, LIN>(a, bc, tid, lds, sig0); break;
+        case 2: ntt_phase_sub<2, LIN>(a, bc, tid, lds, sig0); break;
 #if LSA_NTT_MAX_RHO >= 4
-        case 3: ntt_phase_sub<3>(a, bc, tid, lds, sig0); break;
-        default: ntt_phase_sub<4>(a, bc, tid, lds, sig0); break;
+        case 3: ntt_phase_sub<3, LIN>(a, bc, tid, lds, sig0); break;
+        default: ntt_phase_sub<4, LIN>(a, bc, tid, lds, sig0); break;
 #elif LSA_NTT_MAX_RHO == 3
-        default: ntt_phase_sub<3>(a, bc, tid, lds, sig0); break;
+        default: ntt_phase_sub<3, LIN>(a, bc, tid, lds, sig0); break;
 #else
         default: break;
 #endif
     }
+}
+
+LSA_HD void ntt_phase_sub_dyn(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
+    const int beta0 = a.lambda + a.mu - sig0 - rho;
+    if (beta0 == 0 || beta0 >= 4)
+        ntt_phase_sub_sel<true>(a, bc, tid, lds, sig0, rho);
+    else
+        ntt_phase_sub_sel<false>(a, bc, tid, lds, sig0, rho);
 }

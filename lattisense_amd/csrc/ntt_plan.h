@@ -13,7 +13,10 @@ inline NttPlan make_ntt_plan(int logn, int tau_max = 12) {
         p.npass = 1;
         p.pass[0] = {0, logn, 0, logn};
     } else {
-        int mu_a = logn / 2, mu_b = logn - mu_a;
+        // pass A keeps >= 16 columns (128-byte segments) per tile: mu_a <= tau - 4
+        int mu_a = logn / 2;
+        if (mu_a > tau_max - 4) mu_a = tau_max - 4;
+        int mu_b = logn - mu_a;
         p.npass = 2;
         p.pass[0] = {0, mu_a, tau_max - mu_a, tau_max};
         p.pass[1] = {mu_a, mu_b, 0, tau_max};
