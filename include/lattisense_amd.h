@@ -129,6 +129,9 @@ int lsa_set_fuse_tails(lsa_context ctx, int enable);
 /* Two-pass NTTs (N > 2^12) run both passes over a chunk of at most `mib` MiB of limbs before moving on, so that the
  * second pass is served by the 256 MiB Infinity Cache (0 = one launch per pass over the whole batch). */
 int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib);
+/* diagnostic builds only (-DLSA_NTT_DIAG_STAMPS): device buffer of 8192*8 u64 receiving per-workgroup phase time stamps
+ * of every following NTT launch; NULL turns it off.  Ignored by the normal build. */
+int lsa_debug_set_ntt_stamps(lsa_context ctx, void* device_buffer);
 /* Sampled HIP-event timing of the library's own kernel launches, recorded on the stream they are launched on (every
  * `stride`-th launch of each kind gets an event pair).  kind: 0 NTT pass, 1 base conversion, 2 key-switch MAC,
  * 3 tensor, 4 other element-wise.  total_bytes = ALGORITHMIC bytes of the sampled launches. */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "lsa_set_dual_stream": (c_int, [c_vp, c_int]),
     "lsa_set_fuse_tails": (c_int, [c_vp, c_int]),
     "lsa_set_ntt_chunk_mib": (c_int, [c_vp, c_int]),
+    "lsa_debug_set_ntt_stamps": (c_int, [c_vp, c_vp]),
     "lsa_profile_begin": (c_int, [c_vp, c_int]),
     "lsa_profile_end": (c_int, [c_vp]),
     "lsa_profile_read": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),

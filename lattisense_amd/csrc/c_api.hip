@@ -338,6 +338,10 @@ int lsa_set_fuse_tails(lsa_context ctx, int enable) {
 int lsa_set_dual_stream(lsa_context ctx, int enable) {
     return guard([&] { C(ctx).dual_stream = enable ? 1 : 0; });
 }
+int lsa_debug_set_ntt_stamps(lsa_context ctx, void* device_buffer) {
+    return guard([&] { C(ctx).ntt_diag = static_cast<unsigned long long*>(device_buffer); });
+}
+
 int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib) {
     return guard([&] {
         LSA_REQUIRE(mib >= 0, "chunk size must be >= 0");

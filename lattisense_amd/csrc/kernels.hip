@@ -14,6 +14,15 @@ static constexpr int TPB = 256;
 #define LSA_NTT_TILES_PER_WG 1   // >1: a workgroup walks this many consecutive tiles, prefetching tile k+1 during tile k
 #endif
 
+#if defined(LSA_NTT_DIAG_STAMPS)   // diagnostic build: shader-clock stamp k of this workgroup (first 8192 workgroups)
+#define LSA_STAMP(k)                                                                               \
+    do {                                                                                           \
+        if (a.diag && threadIdx.x == 0 && blockIdx.x < 8192) a.diag[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define LSA_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     const int np = (a.mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO, base = a.mu / np, extra = a.mu % np;
     if (!a.inverse) {
@@ -21,7 +30,9 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
         for (int i = 0; i < np; i++) {
             const int rho = base + (i < extra ? 1 : 0);
             ntt_phase_sub_dyn(a, bc, tid, lds, sig, rho);
+            LSA_STAMP(3 + 2 * i);
             __syncthreads();
+            LSA_STAMP(4 + 2 * i);
             sig += rho;
         }
     } else {
@@ -58,14 +69,18 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(Ntt
     if (lds[lds_addr(tid)] == 0x123456789abcull) a.dst[bc.base_dst + tid] = 1;   // keeps the work alive
     return;
 #endif
+    LSA_STAMP(0);
     ntt_phase_load(a, bc, tid, lds);
+    LSA_STAMP(1);
     __syncthreads();
+    LSA_STAMP(2);
 #if defined(LSA_NTT_DIAG_COPY_ONLY)   // diagnostic build: data movement of the pass structure without butterflies
     ntt_phase_store(a, bc, tid, lds);
     return;
 #endif
     ntt_butterfly_phases(a, bc, tid, lds);
     ntt_phase_store(a, bc, tid, lds);
+    LSA_STAMP(7);
 #else
     // software-pipelined walk over consecutive tiles (same limb and tile index, different batch items: same twiddles)
     const long long first = (long long)blockIdx.x * LSA_NTT_TILES_PER_WG;
@@ -111,6 +126,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
     a.tw = inverse ? c.d_psiinv : c.d_psi;
     a.scale = c.d_scale;
     a.twd = inverse ? c.d_psiinv_d : c.d_psi_d;
+    a.diag = c.ntt_diag;
     a.scaled = c.d_scale_d;
     a.allow_fp64 = c.fp64_ntt;
     if (fz) {

@@ -86,6 +86,7 @@ struct Context {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void fork_aux(hipStream_t s);   // aux stream waits for everything enqueued on s so far
     void join_aux(hipStream_t s);   // s waits for everything enqueued on the aux stream
+    unsigned long long* ntt_diag = nullptr;   // device buffer for LSA_NTT_DIAG_STAMPS builds (8 stamps per workgroup)
     int ntt_chunk_mib = 0;          // >0: two-pass NTTs run pass A+B per chunk of this many MiB (Infinity-Cache reuse)
 
     // sampled HIP-event timing of kernel launches (bench.py roofline leg); off unless lsa_profile_begin was called

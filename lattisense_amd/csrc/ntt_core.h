@@ -72,6 +72,7 @@ struct NttPassArgs {
     u64* fz_out;
     const u64* fz_last;
     long long fz_a_stride, fz_base_stride, fz_out_stride, fz_last_stride;
+    unsigned long long* diag;   // diagnostic builds (LSA_NTT_DIAG_STAMPS): per-workgroup phase time stamps, else unused
     unsigned char mod_of[LSA_MAX_PERIOD];
 };
 
@@ -104,16 +105,28 @@ LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
     return c;
 }
 
-// local tile index l -> element index inside the limb
+// local tile index l -> element index inside the limb (all extents are powers of two: shifts only)
 LSA_HD int ntt_global_index(const NttPassArgs& a, int tile, int l) {
     if (a.lambda == 0) return (tile << a.tau) + l;  // contiguous tile
-    int lo_bits = a.logn - a.s_lo - a.mu;           // >= lambda
-    int C = 1 << a.lambda;
-    int blocks_per_hi = 1 << (lo_bits - a.lambda);
-    int hi = tile / blocks_per_hi, lob = tile % blocks_per_hi;
-    int r = l >> a.lambda, c = l & (C - 1);
-    return (hi << (a.logn - a.s_lo)) + (r << lo_bits) + lob * C + c;
+    const int lo_bits = a.logn - a.s_lo - a.mu;     // >= lambda
+    const int bph_bits = lo_bits - a.lambda;        // log2(column blocks per hi index)
+    const int hi = tile >> bph_bits, lob = tile & ((1 << bph_bits) - 1);
+    const int r = l >> a.lambda, c = l & ((1 << a.lambda) - 1);
+    return (hi << (a.logn - a.s_lo)) + (r << lo_bits) + (lob << a.lambda) + c;
 }
+// the same map with the per-tile part hoisted: x(l) = base + ((l >> lambda) << rshift) + (l & cmask)
+struct NttTileMap {
+    int base, lambda, rshift, cmask;
+};
+LSA_HD NttTileMap ntt_tile_map(const NttPassArgs& a, int tile) {
+    NttTileMap m;
+    m.base = ntt_global_index(a, tile, 0);
+    m.lambda = a.lambda;
+    m.rshift = a.lambda ? a.logn - a.s_lo - a.mu : 0;
+    m.cmask = (1 << a.lambda) - 1;
+    return m;
+}
+LSA_HD int ntt_tile_index(const NttTileMap& m, int l) { return m.base + ((l >> m.lambda) << m.rshift) + (l & m.cmask); }
 
 // "hi" index (the s_lo leading bits of the element index) of local element l
 LSA_HD int ntt_hi_index(const NttPassArgs& a, int tile, int l) {
@@ -156,43 +169,67 @@ LSA_HD double fp_modmul(double v, double w, double q, double qinv) {
 // x mod q into [-q/2-1, q/2+1] for |x| < 2^53
 LSA_HD double fp_reduce(double x, double q, double qinv) { return __builtin_fma(-__builtin_rint(x * qinv), q, x); }
 
-// phase 0: global -> LDS (2 elements = 16 B per lane per step)
+// phase 0: global -> LDS (2 elements = 16 B per lane per step).  For a full tile (every thread owns exactly
+// LSA_NTT_STAGE_PAIRS pairs) all of a thread's loads are issued before the first one is consumed: a rolled
+// load->convert->ds_write loop serialises one HBM latency per step (measured with the LSA_NTT_DIAG_STAMPS build: 16.3k of
+// a workgroup's 34.6k cycles).
+#define LSA_NTT_STAGE_PAIRS 8   // 16-byte pairs per thread: supports tiles up to 2 * 8 * LSA_NTT_THREADS points
+struct NttLoadFix {   // per-block constants of the load-side conversions
+    bool head, fp;
+    u64 ql, h, hq;
+    ModDev mi;
+};
+LSA_HD u64 ntt_load_fix(const NttLoadFix& f, u64 v) {
+    if (f.head) v = sub_mod(reduce_u64(add_mod(v, f.h, f.ql), f.mi), f.hq, f.mi.q);
+    if (f.fp) v = d_to_bits(u52_to_double(v));  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact
+    return v;
+}
 LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     const u64* g = a.src + bc.base_src;
-    int half = 1 << (a.tau - 1);
-    for (int i = tid; i < half; i += LSA_NTT_THREADS) {
-        int l = 2 * i;
-        int x = ntt_global_index(a, bc.tile, l);
-        u64 v0, v1;
-        const u64* gp = g + x;
-        if (a.fz_pro && a.s_lo == 0)   // fused rescale head: the tile is derived from the (coefficient-domain) last limb
-            gp = a.fz_last + (long long)bc.b * a.fz_last_stride + ((long long)(bc.row / a.fz_limbs) << a.logn) + x;
+    const int half = 1 << (a.tau - 1);
+    NttLoadFix f;
+    f.head = a.fz_pro && a.s_lo == 0;   // fused rescale head: the tile is derived from the (coefficient-domain) last limb
+    f.fp = bc.fp != 0;
+    f.mi = a.mods[bc.mod];
+    f.ql = f.h = f.hq = 0;
+    if (f.head) {
+        g = a.fz_last + (long long)bc.b * a.fz_last_stride + ((long long)(bc.row / a.fz_limbs) << a.logn);
+        f.ql = a.mods[a.fz_ql_mod].q;
+        f.h = (f.ql - 1) >> 1;
+        f.hq = reduce_u64(f.h, f.mi);
+    }
+    const NttTileMap tm = ntt_tile_map(a, bc.tile);
+    if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS) {
+        u64 st[2 * LSA_NTT_STAGE_PAIRS];
+#pragma unroll
+        for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
+            const u64* gp = g + ntt_tile_index(tm, 2 * (tid + p * LSA_NTT_THREADS));
 #if defined(__HIP_DEVICE_COMPILE__)
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(gp);
-        v0 = v.x;
-        v1 = v.y;
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(gp);
+            st[2 * p] = v.x;
+            st[2 * p + 1] = v.y;
 #else
-        v0 = gp[0];
-        v1 = gp[1];
+            st[2 * p] = gp[0];
+            st[2 * p + 1] = gp[1];
 #endif
-        if (a.fz_pro && a.s_lo == 0) {
-            const ModDev ml = a.mods[a.fz_ql_mod], mi = a.mods[bc.mod];
-            const u64 h = (ml.q - 1) >> 1, hq = reduce_u64(h, mi);
-            v0 = sub_mod(reduce_u64(add_mod(v0, h, ml.q), mi), hq, mi.q);
-            v1 = sub_mod(reduce_u64(add_mod(v1, h, ml.q), mi), hq, mi.q);
         }
-        if (bc.fp) {  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact as doubles
-            v0 = d_to_bits(u52_to_double(v0));
-            v1 = d_to_bits(u52_to_double(v1));
+#pragma unroll
+        for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
+            const int l = 2 * (tid + p * LSA_NTT_THREADS);
+            lds[lds_addr(l)] = ntt_load_fix(f, st[2 * p]);
+            lds[lds_addr(l + 1)] = ntt_load_fix(f, st[2 * p + 1]);
         }
-        lds[lds_addr(l)] = v0;
-        lds[lds_addr(l + 1)] = v1;
+        return;
+    }
+    for (int i = tid; i < half; i += LSA_NTT_THREADS) {   // partial tiles (small rings)
+        const u64* gp = g + ntt_tile_index(tm, 2 * i);
+        lds[lds_addr(2 * i)] = ntt_load_fix(f, gp[0]);
+        lds[lds_addr(2 * i + 1)] = ntt_load_fix(f, gp[1]);
     }
 }
 
 // The load phase split in two for software pipelining (async-STAGE split): `fetch` only ISSUES the tile's global loads
 // into registers (they stay in flight while the previous tile's butterflies run), `commit` writes them to LDS later.
-#define LSA_NTT_STAGE_PAIRS 8   // 16-byte pairs per thread: supports tiles up to 2 * 8 * LSA_NTT_THREADS points
 LSA_HD void ntt_phase_fetch(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* stage /*[2*PAIRS]*/) {
     const u64* g = a.src + bc.base_src;
     const int half = 1 << (a.tau - 1);
@@ -229,50 +266,96 @@ LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int ti
     }
 }
 
-// final phase: LDS -> global
+// final phase: LDS -> global.  Full tiles go in chunks of LSA_NTT_STORE_CHUNK pairs per thread: a chunk's LDS reads and
+// (fused tail) operand loads are all issued before the first is consumed, for the same reason as in the load phase.
+#define LSA_NTT_STORE_CHUNK 4
+struct NttStoreFix {   // per-block constants of the store-side conversions
+    bool fp, final_reduce, tail, with_base;
+    u64 q, qinv, k;
+    double qd, qinvd;
+};
+LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
+    if (f.fp) {  // always canonical on store: the next pass reloads exact small integers
+        double r = fp_reduce(d_from_bits(v), f.qd, f.qinvd);
+        if (r < 0) r += f.qd;   // |r| <= q/2 (+ rounding slack): one conditional add lands in [0, q)
+        v = double_to_u52(r);
+    } else if (f.final_reduce) {
+        v = csub(csub(v, 2 * f.q), f.q);
+    }
+    if (f.tail) {   // fused tail: the transformed value is consumed here and never stored
+        v = mont_mul(sub_mod(va, v, f.q), f.k, f.q, f.qinv);
+        if (f.with_base) v = add_mod(v, vb, f.q);
+    }
+    return v;
+}
+LSA_HD void ntt_store_pair(u64* gp, u64 v0, u64 v1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ulonglong2 w;
+    w.x = v0;
+    w.y = v1;
+    *reinterpret_cast<ulonglong2*>(gp) = w;
+#else
+    gp[0] = v0;
+    gp[1] = v1;
+#endif
+}
 LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64* lds) {
     u64* g = a.dst + bc.base_dst;
-    const u64 q = a.mods[bc.mod].q;
-    const double qd = (double)q, qinvd = 1.0 / qd;
-    int half = 1 << (a.tau - 1);
-    for (int i = tid; i < half; i += LSA_NTT_THREADS) {
-        int l = 2 * i;
-        int x = ntt_global_index(a, bc.tile, l);
-        u64 v0 = lds[lds_addr(l)], v1 = lds[lds_addr(l + 1)];
-        if (bc.fp) {  // always canonical on store: the next pass reloads exact small integers
-            double r0 = fp_reduce(d_from_bits(v0), qd, qinvd), r1 = fp_reduce(d_from_bits(v1), qd, qinvd);
-            if (r0 < 0) r0 += qd;   // |r| <= q/2 (+ rounding slack): one conditional add lands in [0, q)
-            if (r1 < 0) r1 += qd;
-            v0 = double_to_u52(r0);
-            v1 = double_to_u52(r1);
-        } else if (a.final_reduce) {
-            v0 = csub(csub(v0, 2 * q), q);
-            v1 = csub(csub(v1, 2 * q), q);
-        }
-        u64* gp = g + x;
-        if (a.fz_epi && a.final_reduce) {   // fused tail: the transformed value is consumed here and never stored
-            const ModDev md = a.mods[bc.mod];
-            const int poly = bc.row / a.fz_limbs, limb = bc.row % a.fz_limbs;
-            const u64* pa = a.fz_a + (long long)bc.b * a.fz_a_stride + (((long long)poly * a.fz_a_rpp + limb) << a.logn) + x;
-            const u64 k = a.fz_k[limb];
-            v0 = mont_mul(sub_mod(pa[0], v0, q), k, q, md.qinv);
-            v1 = mont_mul(sub_mod(pa[1], v1, q), k, q, md.qinv);
-            if (a.fz_base && poly < a.fz_base_polys) {
-                const u64* pb = a.fz_base + (long long)bc.b * a.fz_base_stride + (((long long)poly * a.fz_base_rpp + limb) << a.logn) + x;
-                v0 = add_mod(v0, pb[0], q);
-                v1 = add_mod(v1, pb[1], q);
+    const ModDev md = a.mods[bc.mod];
+    const int half = 1 << (a.tau - 1);
+    NttStoreFix f;
+    f.fp = bc.fp != 0;
+    f.final_reduce = a.final_reduce != 0;
+    f.tail = a.fz_epi && a.final_reduce;
+    f.q = md.q;
+    f.qinv = md.qinv;
+    f.qd = (double)md.q;
+    f.qinvd = 1.0 / f.qd;
+    f.k = 0;
+    const int poly = f.tail ? bc.row / a.fz_limbs : 0, limb = f.tail ? bc.row % a.fz_limbs : 0;
+    f.with_base = f.tail && a.fz_base && poly < a.fz_base_polys;
+    const u64* pa = g;   // placeholders when there is no fused tail (never dereferenced)
+    const u64* pb = g;
+    if (f.tail) {
+        pa = a.fz_a + (long long)bc.b * a.fz_a_stride + (((long long)poly * a.fz_a_rpp + limb) << a.logn);
+        f.k = a.fz_k[limb];
+        g = a.fz_out + (long long)bc.b * a.fz_out_stride + (((long long)poly * a.fz_out_rpp + limb) << a.logn);
+        if (f.with_base) pb = a.fz_base + (long long)bc.b * a.fz_base_stride + (((long long)poly * a.fz_base_rpp + limb) << a.logn);
+    }
+    const NttTileMap tm = ntt_tile_map(a, bc.tile);
+    if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS) {
+        for (int p0 = 0; p0 < LSA_NTT_STAGE_PAIRS; p0 += LSA_NTT_STORE_CHUNK) {
+            u64 v[2 * LSA_NTT_STORE_CHUNK], va[2 * LSA_NTT_STORE_CHUNK], vb[2 * LSA_NTT_STORE_CHUNK];
+            int xs[LSA_NTT_STORE_CHUNK];
+#pragma unroll
+            for (int p = 0; p < LSA_NTT_STORE_CHUNK; p++) {
+                const int l = 2 * (tid + (p0 + p) * LSA_NTT_THREADS);
+                const int x = ntt_tile_index(tm, l);
+                xs[p] = x;
+                v[2 * p] = lds[lds_addr(l)];
+                v[2 * p + 1] = lds[lds_addr(l + 1)];
+                va[2 * p] = va[2 * p + 1] = vb[2 * p] = vb[2 * p + 1] = 0;
+                if (f.tail) {
+                    va[2 * p] = pa[x];
+                    va[2 * p + 1] = pa[x + 1];
+                }
+                if (f.with_base) {
+                    vb[2 * p] = pb[x];
+                    vb[2 * p + 1] = pb[x + 1];
+                }
             }
-            gp = a.fz_out + (long long)bc.b * a.fz_out_stride + (((long long)poly * a.fz_out_rpp + limb) << a.logn) + x;
+#pragma unroll
+            for (int p = 0; p < LSA_NTT_STORE_CHUNK; p++)
+                ntt_store_pair(g + xs[p], ntt_store_fix(f, v[2 * p], va[2 * p], vb[2 * p]),
+                               ntt_store_fix(f, v[2 * p + 1], va[2 * p + 1], vb[2 * p + 1]));
         }
-#if defined(__HIP_DEVICE_COMPILE__)
-        ulonglong2 v;
-        v.x = v0;
-        v.y = v1;
-        *reinterpret_cast<ulonglong2*>(gp) = v;
-#else
-        gp[0] = v0;
-        gp[1] = v1;
-#endif
+        return;
+    }
+    for (int i = tid; i < half; i += LSA_NTT_THREADS) {   // partial tiles (small rings)
+        const int x = ntt_tile_index(tm, 2 * i);
+        const u64 a0 = f.tail ? pa[x] : 0, a1 = f.tail ? pa[x + 1] : 0;
+        const u64 b0 = f.with_base ? pb[x] : 0, b1 = f.with_base ? pb[x + 1] : 0;
+        ntt_store_pair(g + x, ntt_store_fix(f, lds[lds_addr(2 * i)], a0, b0), ntt_store_fix(f, lds[lds_addr(2 * i + 1)], a1, b1));
     }
 }
 
