@@ -147,6 +147,7 @@ const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::ve
         K->shat_inv_m[i] = to_mont_host(inv_mod(pr, qi), qi);
         K->half_src[i] = mul_mod_host(qi - 1, (qi + 1) >> 1, qi);  // floor(S/2) mod q_i with S == 0 mod q_i, S odd
         K->qf[i] = (double)qi;
+        K->rf[i] = 1.0 / (double)qi;
     }
     for (int j = 0; j < nd; j++) {
         const u64 pj = T.mod[dst[j]];

@@ -347,7 +347,6 @@ void launch_tensor(Context& c, const u64* a, const u64* b, u64* d, int batch, lo
 // ------------------------------------------------------------------------------------------------ exact base conversion
 //  y_i = x_i*(S/q_i)^-1 mod q_i ; v = floor(sum double(y_i)/double(q_i)) ;
 // out_j = sum_i y_i*(S/q_i) - v*S mod p_j   [centered: x+floor(S/2) in, -floor(S/2) out]
-#define LSA_BC_TGT_PER_BLOCK 7
 struct BaseConvArgs {
     const BaseConvConsts* k;
     const ModDev* mods;
@@ -358,43 +357,56 @@ struct BaseConvArgs {
     BaseConvRows rows;
 };
 
-// NSMAX = compile-time bound of the source-limb loops (registers for y[] scale with it; dispatched from ns)
-template <int NSMAX>
+// NSMAX = compile-time bound of the source-limb loops (registers for y[] scale with it; dispatched from ns); EXACT: ns ==
+// NSMAX, so the source loads carry no guard and are all in flight before the first is consumed.  The target loop has a
+// fixed trip count (the tail group repeats its last target: same value stored twice by the same thread), so the per-target
+// constants are fetched up front instead of one scalar-load latency chain per target.
+template <int NSMAX, bool EXACT, int TGT>
 __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
     const BaseConvConsts& K = *g.k;
     const int x = (blockIdx.x * TPB + threadIdx.x) * 2;
     const long long b = blockIdx.y;
     const u64* src = g.src + b * g.ssrc + x;
     u64* dst = g.dst + b * g.sdst + x;
-    const int ns = K.ns, nd = K.nd;
+    const int ns = EXACT ? NSMAX : K.ns, nd = K.nd;
+    ulonglong2 xin[NSMAX];
+#pragma unroll
+    for (int i = 0; i < NSMAX; i++)
+        if (EXACT || i < ns) xin[i] = ld2(src + ((long long)g.rows.src_row[i] << g.logn));
     u64 y[NSMAX][2];
     double vf0 = 0.0, vf1 = 0.0;
 #pragma unroll
     for (int i = 0; i < NSMAX; i++) {
-        if (i < ns) {
+        if (EXACT || i < ns) {
             const ModDev m = g.mods[K.src_mod[i]];
-            ulonglong2 v = ld2(src + ((long long)g.rows.src_row[i] << g.logn));
+            ulonglong2 v = xin[i];
             if (K.centered) {
                 v.x = add_mod(v.x, K.half_src[i], m.q);
                 v.y = add_mod(v.y, K.half_src[i], m.q);
             }
             y[i][0] = mont_mul(v.x, K.shat_inv_m[i], m.q, m.qinv);
             y[i][1] = mont_mul(v.y, K.shat_inv_m[i], m.q, m.qinv);
-            const double qf = K.qf[i];
-            vf0 += (double)y[i][0] / qf;   // IEEE division + sequential adds: same float sequence as the oracle
-            vf1 += (double)y[i][1] / qf;
+            // y/q correctly rounded == the oracle's IEEE division, in 3 operations (Markstein: with r = RN(1/q) and
+            // q0 = RN(y*r), RN(q0 + (y - q0*q)*r) is the correctly rounded quotient; q's significand is not all ones),
+            // then sequential adds: same float sequence as the oracle
+            const double qf = K.qf[i], rf = K.rf[i];
+            const double a0 = (double)y[i][0], a1 = (double)y[i][1];
+            const double e0 = a0 * rf, e1 = a1 * rf;
+            vf0 += __builtin_fma(__builtin_fma(-e0, qf, a0), rf, e0);
+            vf1 += __builtin_fma(__builtin_fma(-e1, qf, a1), rf, e1);
         }
     }
     const int v0 = (int)(u64)vf0, v1 = (int)(u64)vf1;
-    // targets are split over blockIdx.z (each block recomputes the cheap y_i/v and converts LSA_BC_TGT_PER_BLOCK targets)
-    const int j0 = blockIdx.z * LSA_BC_TGT_PER_BLOCK;
-    const int j1 = min(nd, j0 + LSA_BC_TGT_PER_BLOCK);
-    for (int j = j0; j < j1; j++) {
+    // targets are split over blockIdx.z (each block recomputes y_i/v and converts TGT targets)
+    const int j0 = blockIdx.z * TGT;
+#pragma unroll
+    for (int jj = 0; jj < TGT; jj++) {
+        const int j = min(j0 + jj, nd - 1);
         const ModDev m = g.mods[K.dst_mod[j]];
         u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0, r0 = 0, r1 = 0;
 #pragma unroll
         for (int i = 0; i < NSMAX; i++) {
-            if (i < ns) {
+            if (EXACT || i < ns) {
                 const u64 w = K.shat_m[j][i];
                 mac128(h0, l0, y[i][0], w);
                 mac128(h1, l1, y[i][1], w);
@@ -417,6 +429,30 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
     }
 }
 
+template <int NSMAX, int TGT>
+static void launch_baseconv_nt(int ns, int nd, dim3 grid, hipStream_t s, const BaseConvArgs& g) {
+    grid.z = (unsigned)((nd + TGT - 1) / TGT);
+    if (ns == NSMAX) hipLaunchKernelGGL((k_baseconv<NSMAX, true, TGT>), grid, dim3(TPB), 0, s, g);
+    else hipLaunchKernelGGL((k_baseconv<NSMAX, false, TGT>), grid, dim3(TPB), 0, s, g);
+}
+// targets per block: the candidate with the least total work ceil(nd/T) * (Y + T*C), Y = y/v phase ~ 2.5 target conversions
+template <int NSMAX>
+static void launch_baseconv_ns(int ns, int nd, dim3 grid, hipStream_t s, const BaseConvArgs& g) {
+    const int cand[3] = {4, 7, 13};
+    int best = 4;
+    double best_cost = 1e30;
+    for (int T : cand) {
+        const double cost = (double)((nd + T - 1) / T) * (2.5 + T);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = T;
+        }
+    }
+    if (best == 4) launch_baseconv_nt<NSMAX, 4>(ns, nd, grid, s, g);
+    else if (best == 7) launch_baseconv_nt<NSMAX, 7>(ns, nd, grid, s, g);
+    else launch_baseconv_nt<NSMAX, 13>(ns, nd, grid, s, g);
+}
+
 void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
                      long long ssrc, long long sdst, hipStream_t s) {
     if (batch <= 0) return;
@@ -430,17 +466,16 @@ void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows
     g.logn = c.logn;
     g.rows = rows;
     ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns + k->nd), s);
-    const unsigned gz = (unsigned)((k->nd + LSA_BC_TGT_PER_BLOCK - 1) / LSA_BC_TGT_PER_BLOCK);
-    const dim3 grid((unsigned)(c.n / (2 * TPB)), (unsigned)batch, gz);
-    const int ns = k->ns;
-    if (ns <= 1) hipLaunchKernelGGL(k_baseconv<1>, grid, dim3(TPB), 0, s, g);
-    else if (ns <= 2) hipLaunchKernelGGL(k_baseconv<2>, grid, dim3(TPB), 0, s, g);
-    else if (ns <= 3) hipLaunchKernelGGL(k_baseconv<3>, grid, dim3(TPB), 0, s, g);
-    else if (ns <= 4) hipLaunchKernelGGL(k_baseconv<4>, grid, dim3(TPB), 0, s, g);
-    else if (ns <= 5) hipLaunchKernelGGL(k_baseconv<5>, grid, dim3(TPB), 0, s, g);
-    else if (ns <= 8) hipLaunchKernelGGL(k_baseconv<8>, grid, dim3(TPB), 0, s, g);
-    else if (ns <= 12) hipLaunchKernelGGL(k_baseconv<12>, grid, dim3(TPB), 0, s, g);
-    else hipLaunchKernelGGL(k_baseconv<LSA_BC_MAX_SRC>, grid, dim3(TPB), 0, s, g);
+    const dim3 grid((unsigned)(c.n / (2 * TPB)), (unsigned)batch, 1);
+    const int ns = k->ns, nd = k->nd;
+    if (ns <= 1) launch_baseconv_ns<1>(ns, nd, grid, s, g);
+    else if (ns <= 2) launch_baseconv_ns<2>(ns, nd, grid, s, g);
+    else if (ns <= 3) launch_baseconv_ns<3>(ns, nd, grid, s, g);
+    else if (ns <= 4) launch_baseconv_ns<4>(ns, nd, grid, s, g);
+    else if (ns <= 5) launch_baseconv_ns<5>(ns, nd, grid, s, g);
+    else if (ns <= 8) launch_baseconv_ns<8>(ns, nd, grid, s, g);
+    else if (ns <= 12) launch_baseconv_ns<12>(ns, nd, grid, s, g);
+    else launch_baseconv_ns<LSA_BC_MAX_SRC>(ns, nd, grid, s, g);
     LSA_HIP(hipGetLastError());
 }
 

@@ -47,6 +47,7 @@ struct BaseConvConsts {
     u64 shat_inv_m[LSA_BC_MAX_SRC];                 // (S/q_i)^-1 mod q_i, Montgomery form
     u64 half_src[LSA_BC_MAX_SRC];                   // floor(S/2) mod q_i
     double qf[LSA_BC_MAX_SRC];                      // (double) q_i
+    double rf[LSA_BC_MAX_SRC];                      // RN(1 / qf): reciprocal for the 3-operation exact division
     u64 shat_m[LSA_BC_MAX_DST][LSA_BC_MAX_SRC];     // (S/q_i) mod p_j, Montgomery form
     u64 vs[LSA_BC_MAX_DST][LSA_BC_MAX_SRC + 1];     // v*S mod p_j, v = 0..ns
     u64 half_dst[LSA_BC_MAX_DST];                   // floor(S/2) mod p_j
