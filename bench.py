@@ -260,7 +260,7 @@ def main():
         roofline = {"kernel": "k_ntt_pass", "bound": "hbm", "achieved": ntt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": ntt["achieved_GBps"] / HBM_PEAK_GBPS, "traffic": None,
                     "avg_launch_us": ntt["avg_launch_us"], "launches_per_step": ntt["launches_per_step"],
-                    "sampling": "HIP event pair around every %d-th launch, on the launch stream" % args.prof_stride}
+                    "sampling": "HIP event pair around one launch in %d (hash-picked), on the launch stream" % args.prof_stride}
 
     # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed
     # rocprofv3 --pmc passes of this same command (tools/profile.sh -> profiles/), matched on workload and batch.

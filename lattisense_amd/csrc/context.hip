@@ -124,8 +124,10 @@ u64* Context::workspace2(size_t words, hipStream_t s) {
     return ws2;
 }
 
-const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered) {
+const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered,
+                                      bool pinv_scaled) {
     std::string key = centered ? "c" : "u";
+    if (pinv_scaled) key += "s";
     for (int x : src) key += "|" + std::to_string(x);
     key += "->";
     for (int x : dst) key += "|" + std::to_string(x);
@@ -154,14 +156,20 @@ const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::ve
         K->dst_mod[j] = dst[j];
         u64 all = 1 % pj;
         for (int l = 0; l < ns; l++) all = mul_mod_host(all, T.mod[src[l]] % pj, pj);
+        u64 scale = 1 % pj;   // pinv_scaled: every constant of the (linear) output formula times P^-1 mod p_j
+        if (pinv_scaled && j + 1 < nd) {
+            u64 pp = 1;
+            for (int l = 0; l < np; l++) pp = mul_mod_host(pp, T.mod[p_mod(l)] % pj, pj);
+            scale = inv_mod(pp, pj);
+        }
         for (int i = 0; i < ns; i++) {
             u64 pr = 1 % pj;
             for (int l = 0; l < ns; l++)
                 if (l != i) pr = mul_mod_host(pr, T.mod[src[l]] % pj, pj);
-            K->shat_m[j][i] = to_mont_host(pr, pj);
+            K->shat_m[j][i] = to_mont_host(mul_mod_host(pr, scale, pj), pj);
         }
-        for (int v = 0; v <= ns; v++) K->vs[j][v] = mul_mod_host((u64)v % pj, all, pj);
-        K->half_dst[j] = mul_mod_host((all + pj - 1 % pj) % pj, (pj + 1) >> 1, pj);
+        for (int v = 0; v <= ns; v++) K->vs[j][v] = mul_mod_host(mul_mod_host((u64)v % pj, all, pj), scale, pj);
+        K->half_dst[j] = mul_mod_host(mul_mod_host((all + pj - 1 % pj) % pj, (pj + 1) >> 1, pj), scale, pj);
     }
     use_device();
     BaseConvConsts* d = nullptr;

@@ -24,6 +24,8 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
     a.scaled = T.scale_d.data();
     a.allow_fp64 = allow_fp64;
     a.period = period;
+    a.row0 = 0;
+    a.row_step = 1;
     for (int i = 0; i < period; i++) a.mod_of[i] = mod_of[i];
     for (int step = 0; step < plan.npass; step++) {
         int k = inverse ? plan.npass - 1 - step : step;

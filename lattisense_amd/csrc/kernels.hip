@@ -149,14 +149,19 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         a.fz_out_rpp = fz->out_rpp;
         a.fz_last = fz->last;
         a.fz_last_stride = fz->last_stride;
+        a.fz_last_rpp = fz->last_rpp;
+        a.fz_k2 = fz->k2;
+        LSA_REQUIRE(fz->epi != 2 || fz->k2, "merged tail needs its second factor");
     }
     a.period = rm.period;
+    a.row0 = rm.row0;
+    a.row_step = rm.row_step;
     for (int i = 0; i < rm.period; i++) {
         LSA_REQUIRE(rm.mod_of[i] == LSA_ROW_SKIP || rm.mod_of[i] < c.nmod, "ntt: modulus index out of range");
         a.mod_of[i] = rm.mod_of[i];
     }
     int active_rows = 0;
-    for (int r = 0; r < rows; r++) active_rows += rm.mod_of[r % rm.period] != LSA_ROW_SKIP;
+    for (int r = 0; r < rows; r++) active_rows += rm.mod_of[(rm.row0 + r * rm.row_step) % rm.period] != LSA_ROW_SKIP;
     // Two-pass transforms: run both passes on a chunk of the batch that fits the 256 MiB Infinity Cache before moving
     // on, so the second pass reads what the first just wrote from the memory-side cache instead of HBM.
     int chunk = batch;

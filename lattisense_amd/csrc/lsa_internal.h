@@ -121,7 +121,9 @@ struct Context {
     u64* workspace2(size_t words, hipStream_t s);
     int p_mod(int i) const { return nq + i; }
     int aux_mod(int i) const { return nq + np + i; }
-    const BaseConvPlan* baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered);
+    // pinv_scaled: the outputs of every target but the last are multiplied by P^-1 mod p_j (merged ModDown + rescale)
+    const BaseConvPlan* baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered,
+                                 bool pinv_scaled = false);
     const u64* pinv_vec(int level);
     const u64* qlinv_vec(int level);
     const u32* ntt_perm(u64 g);
@@ -139,7 +141,9 @@ struct ProfScope {
     ProfScope(Context& c_, int kid, double bytes, hipStream_t s_) : c(c_), s(s_) {
         if (!c.prof_on) return;
         const long long idx = c.prof_launched[kid]++;
-        if (idx % c.prof_stride != 0) return;
+        // every stride-th launch on average, picked by a hash of the launch index: a fixed stride would lock onto the
+        // period of the operator's launch sequence and always time the same launch types
+        if (c.prof_stride > 1 && ((unsigned long long)(idx + 1) * 0x9E3779B97F4A7C15ull >> 33) % (unsigned)c.prof_stride != 0) return;
         auto take = [&]() {
             hipEvent_t e;
             if (!c.prof_pool.empty()) {
@@ -168,6 +172,7 @@ struct ProfScope {
 struct RowMap {   // rows of a batch item -> modulus index (0xFF = skip)
     int period;
     unsigned char mod_of[LSA_MAX_PERIOD];
+    int row0 = 0, row_step = 1;   // the launch's i-th row is row row0 + i*row_step of the batch item (mod_of[row % period])
 };
 
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch_stride, int rows, const RowMap& rm,
@@ -187,6 +192,8 @@ struct NttFusion {
     int out_rpp = 0;
     const u64* last = nullptr;
     long long last_stride = 0;
+    int last_rpp = 1;            // rows between the polynomials' last limbs in `last`
+    const u64* k2 = nullptr;     // epi == 2: out = (a*k - v + base) * k2
 };
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
                 const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz = nullptr);

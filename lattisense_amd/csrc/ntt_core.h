@@ -58,17 +58,21 @@ struct NttPassArgs {
     int final_reduce;     // store fully reduced [0,q)
     int allow_fp64;       // 0 forces the integer engine for every limb
     int period;           // row r uses modulus mod_of[r % period]
+    int row0, row_step;   // the launch's i-th row is row r = row0 + i * row_step of the batch item
     // ---- fused element-wise tails (rows of the transformed buffer are [poly][fz_limbs]):
     // epilogue of the LAST pass of a forward transform, replaces the plain store of the transformed value v:
     //   fz_epi = 1:  out[poly][limb] = (fz_a[poly][limb] - v) * fz_k[limb]  (+ fz_base[poly][limb] if poly < fz_base_polys)
     //                (ModDown tail: (acc_Q - conv) * P^-1 + d;   rescale tail: (c - t) * q_l^-1)
     // prologue of the FIRST pass, replaces the plain load:
-    //   fz_pro = 1:  in = ((fz_last[poly] + h) mod q_l) mod q_limb - (h mod q_limb),  h = (q_l - 1)/2  (rescale head)
+    //   fz_pro = 1:  in = lift = ((fz_last[poly] + h) mod q_l) mod q_limb - (h mod q_limb),  h = (q_l - 1)/2  (rescale head)
+    //   fz_pro = 2:  in = src + lift   (merged ModDown + rescale: one transform of conv*P^-1 + lift serves both steps)
+    //   fz_epi = 2:  out = (fz_a * fz_k - v + fz_base) * fz_k2   (its tail: (acc*P^-1 - NTT(in) + base) * q_l^-1)
     int fz_epi, fz_pro, fz_limbs, fz_base_polys, fz_ql_mod;
-    int fz_a_rpp, fz_base_rpp, fz_out_rpp;
+    int fz_a_rpp, fz_base_rpp, fz_out_rpp, fz_last_rpp;
     const u64* fz_a;
     const u64* fz_base;
     const u64* fz_k;
+    const u64* fz_k2;
     u64* fz_out;
     const u64* fz_last;
     long long fz_a_stride, fz_base_stride, fz_out_stride, fz_last_stride;
@@ -94,7 +98,7 @@ LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
     int b = (int)(bid % a.batch);
     long long rt = bid / a.batch;
     c.tile = (int)(rt % tiles);
-    int row = (int)(rt / tiles);
+    int row = a.row0 + (int)(rt / tiles) * a.row_step;
     c.base_src = (long long)b * a.src_stride + ((long long)row << a.logn);
     c.base_dst = (long long)b * a.dst_stride + ((long long)row << a.logn);
     c.mod = a.mod_of[row % a.period];
@@ -175,56 +179,92 @@ LSA_HD double fp_reduce(double x, double q, double qinv) { return __builtin_fma(
 // a workgroup's 34.6k cycles).
 #define LSA_NTT_STAGE_PAIRS 8   // 16-byte pairs per thread: supports tiles up to 2 * 8 * LSA_NTT_THREADS points
 struct NttLoadFix {   // per-block constants of the load-side conversions
-    bool head, fp;
+    bool head, add, fp, near;
     u64 ql, h, hq;
     ModDev mi;
 };
-LSA_HD u64 ntt_load_fix(const NttLoadFix& f, u64 v) {
-    if (f.head) v = sub_mod(reduce_u64(add_mod(v, f.h, f.ql), f.mi), f.hq, f.mi.q);
+// v: the tile's own element; t: the last limb's element at the same position (head modes only)
+LSA_HD u64 ntt_load_fix(const NttLoadFix& f, u64 v, u64 t) {
+    if (f.head) {
+        const u64 c = add_mod(t, f.h, f.ql);   // centred remainder + h, in [0, q_l)
+        // chain primes are within a factor two of each other almost always: one conditional subtraction then replaces
+        // the general reduction
+        const u64 lift = sub_mod(f.near ? csub(c, f.mi.q) : reduce_u64(c, f.mi), f.hq, f.mi.q);
+        v = f.add ? add_mod(v, lift, f.mi.q) : lift;
+    }
     if (f.fp) v = d_to_bits(u52_to_double(v));  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact
     return v;
 }
 LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     const u64* g = a.src + bc.base_src;
+    const u64* gl = g;   // last-limb source of the head modes
     const int half = 1 << (a.tau - 1);
     NttLoadFix f;
     f.head = a.fz_pro && a.s_lo == 0;   // fused rescale head: the tile is derived from the (coefficient-domain) last limb
+    f.add = f.head && a.fz_pro == 2;
     f.fp = bc.fp != 0;
     f.mi = a.mods[bc.mod];
     f.ql = f.h = f.hq = 0;
+    f.near = false;
     if (f.head) {
-        g = a.fz_last + (long long)bc.b * a.fz_last_stride + ((long long)(bc.row / a.fz_limbs) << a.logn);
+        gl = a.fz_last + (long long)bc.b * a.fz_last_stride + ((long long)(bc.row / a.fz_limbs) * a.fz_last_rpp << a.logn);
+        if (!f.add) g = gl;
         f.ql = a.mods[a.fz_ql_mod].q;
         f.h = (f.ql - 1) >> 1;
         f.hq = reduce_u64(f.h, f.mi);
+        f.near = f.ql <= 2 * f.mi.q;
     }
     const NttTileMap tm = ntt_tile_map(a, bc.tile);
-    if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS) {
+    if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS && !f.add) {
+        NttLoadFix f1 = f;
+        f1.add = false;   // known here: keeps the two-operand arithmetic out of this path's 16 unrolled copies
         u64 st[2 * LSA_NTT_STAGE_PAIRS];
 #pragma unroll
         for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
-            const u64* gp = g + ntt_tile_index(tm, 2 * (tid + p * LSA_NTT_THREADS));
+            const int x = ntt_tile_index(tm, 2 * (tid + p * LSA_NTT_THREADS));
 #if defined(__HIP_DEVICE_COMPILE__)
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(gp);
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g + x);
             st[2 * p] = v.x;
             st[2 * p + 1] = v.y;
 #else
-            st[2 * p] = gp[0];
-            st[2 * p + 1] = gp[1];
+            st[2 * p] = g[x];
+            st[2 * p + 1] = g[x + 1];
 #endif
         }
 #pragma unroll
         for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
             const int l = 2 * (tid + p * LSA_NTT_THREADS);
-            lds[lds_addr(l)] = ntt_load_fix(f, st[2 * p]);
-            lds[lds_addr(l + 1)] = ntt_load_fix(f, st[2 * p + 1]);
+            lds[lds_addr(l)] = ntt_load_fix(f1, st[2 * p], st[2 * p]);
+            lds[lds_addr(l + 1)] = ntt_load_fix(f1, st[2 * p + 1], st[2 * p + 1]);
+        }
+        return;
+    }
+    if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS) {   // two operands per element: half the pairs per round
+        constexpr int CH = LSA_NTT_STAGE_PAIRS / 2;
+#pragma unroll 1
+        for (int p0 = 0; p0 < LSA_NTT_STAGE_PAIRS; p0 += CH) {
+            u64 st[2 * CH], sl[2 * CH];
+#pragma unroll
+            for (int p = 0; p < CH; p++) {
+                const int x = ntt_tile_index(tm, 2 * (tid + (p0 + p) * LSA_NTT_THREADS));
+                st[2 * p] = g[x];
+                st[2 * p + 1] = g[x + 1];
+                sl[2 * p] = gl[x];
+                sl[2 * p + 1] = gl[x + 1];
+            }
+#pragma unroll
+            for (int p = 0; p < CH; p++) {
+                const int l = 2 * (tid + (p0 + p) * LSA_NTT_THREADS);
+                lds[lds_addr(l)] = ntt_load_fix(f, st[2 * p], sl[2 * p]);
+                lds[lds_addr(l + 1)] = ntt_load_fix(f, st[2 * p + 1], sl[2 * p + 1]);
+            }
         }
         return;
     }
     for (int i = tid; i < half; i += LSA_NTT_THREADS) {   // partial tiles (small rings)
-        const u64* gp = g + ntt_tile_index(tm, 2 * i);
-        lds[lds_addr(2 * i)] = ntt_load_fix(f, gp[0]);
-        lds[lds_addr(2 * i + 1)] = ntt_load_fix(f, gp[1]);
+        const int x = ntt_tile_index(tm, 2 * i);
+        lds[lds_addr(2 * i)] = ntt_load_fix(f, g[x], gl[x]);
+        lds[lds_addr(2 * i + 1)] = ntt_load_fix(f, g[x + 1], gl[x + 1]);
     }
 }
 
@@ -268,10 +308,12 @@ LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 
 // final phase: LDS -> global.  Full tiles go in chunks of LSA_NTT_STORE_CHUNK pairs per thread: a chunk's LDS reads and
 // (fused tail) operand loads are all issued before the first is consumed, for the same reason as in the load phase.
+#ifndef LSA_NTT_STORE_CHUNK
 #define LSA_NTT_STORE_CHUNK 4
+#endif
 struct NttStoreFix {   // per-block constants of the store-side conversions
-    bool fp, final_reduce, tail, with_base;
-    u64 q, qinv, k;
+    bool fp, final_reduce, tail, with_base, merged;
+    u64 q, qinv, k, k2;
     double qd, qinvd;
 };
 LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
@@ -283,8 +325,14 @@ LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
         v = csub(csub(v, 2 * f.q), f.q);
     }
     if (f.tail) {   // fused tail: the transformed value is consumed here and never stored
-        v = mont_mul(sub_mod(va, v, f.q), f.k, f.q, f.qinv);
-        if (f.with_base) v = add_mod(v, vb, f.q);
+        if (f.merged) {
+            v = sub_mod(mont_mul(va, f.k, f.q, f.qinv), v, f.q);
+            if (f.with_base) v = add_mod(v, vb, f.q);
+            v = mont_mul(v, f.k2, f.q, f.qinv);
+        } else {
+            v = mont_mul(sub_mod(va, v, f.q), f.k, f.q, f.qinv);
+            if (f.with_base) v = add_mod(v, vb, f.q);
+        }
     }
     return v;
 }
@@ -311,7 +359,8 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     f.qinv = md.qinv;
     f.qd = (double)md.q;
     f.qinvd = 1.0 / f.qd;
-    f.k = 0;
+    f.k = f.k2 = 0;
+    f.merged = false;
     const int poly = f.tail ? bc.row / a.fz_limbs : 0, limb = f.tail ? bc.row % a.fz_limbs : 0;
     f.with_base = f.tail && a.fz_base && poly < a.fz_base_polys;
     const u64* pa = g;   // placeholders when there is no fused tail (never dereferenced)
@@ -319,6 +368,8 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     if (f.tail) {
         pa = a.fz_a + (long long)bc.b * a.fz_a_stride + (((long long)poly * a.fz_a_rpp + limb) << a.logn);
         f.k = a.fz_k[limb];
+        f.merged = a.fz_epi == 2;
+        if (f.merged) f.k2 = a.fz_k2[limb];
         g = a.fz_out + (long long)bc.b * a.fz_out_stride + (((long long)poly * a.fz_out_rpp + limb) << a.logn);
         if (f.with_base) pb = a.fz_base + (long long)bc.b * a.fz_base_stride + (((long long)poly * a.fz_base_rpp + limb) << a.logn);
     }

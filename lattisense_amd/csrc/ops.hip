@@ -26,9 +26,23 @@ static size_t ks_ws_rows(const Context& c, int level) {
     return (size_t)L + (size_t)beta * T + 2 * (size_t)T + 2 * (size_t)L;
 }
 
+// Merged tail: the key-switch result is rescaled straight away (CKKS HMult+relin+rescale).  ModDown ends with
+// c_j = (acc_j - NTT(conv_j)) * P^-1 + base_j and the rescale continues with (c_j - NTT(lift_j(t))) * q_l^-1, t = INTT(c_l).
+// Modular arithmetic being exact and the transforms linear, residue for residue
+//   t   = (INTT(acc_l) - conv_l) * P^-1 + INTT(base_l)                      (two extra rows in transforms that run anyway)
+//   out = (acc_j * P^-1 - NTT(conv_j * P^-1 + lift_j(t)) + base_j) * q_l^-1  (ONE forward transform per remaining limb; the
+//                                                                            base conversion emits conv_j * P^-1 directly)
+// 104 limb transforms per operation instead of 128, and 4 fewer launches.
+struct KsRescale {
+    u64* out;          // [2][level][N], level - 1 result
+    long long sout;
+};
+
 // p[h][i] = (h < base_polys ? base[h][i] : 0) + ModDown( sum_d ModUp_d(cx) * key_d[h] )[i]   (all NTT domain)
+// With `rs` (needs fused tails): p is scratch of the same shape and rs->out receives rescale(p).
 static void key_switch(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
-                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s) {
+                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
+                       const KsRescale* rs = nullptr) {
     LSA_REQUIRE(c.np >= 1, "key switching needs at least one special prime");
     LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
     const long long N = c.n;
@@ -87,7 +101,8 @@ static void key_switch(Context& c, int level, const u64* cx, long long scx, cons
         rm.period = 2 * T;
         for (int h = 0; h < 2; h++)
             for (int tl = 0; tl < T; tl++)
-                rm.mod_of[h * T + tl] = tl >= L ? (unsigned char)c.p_mod(tl - L) : LSA_ROW_SKIP;
+                rm.mod_of[h * T + tl] = tl >= L ? (unsigned char)c.p_mod(tl - L)
+                                                : (rs && tl == level ? (unsigned char)level : LSA_ROW_SKIP);
         launch_ntt(c, acc, acc, nb, s_acc, 2 * T, rm, true, s);
     }
     {
@@ -101,11 +116,52 @@ static void key_switch(Context& c, int level, const u64* cx, long long scx, cons
             rows.dst_row[j] = j;
             dst.push_back(j);
         }
-        const BaseConvPlan* k = c.baseconv(src, dst, true);
+        const BaseConvPlan* k = c.baseconv(src, dst, true, rs != nullptr);
         for (int h = 0; h < 2; h++)
             launch_baseconv(c, k, rows, acc + (size_t)h * T * N, conv + (size_t)h * L * N, nb, s_acc, s_conv, s);
     }
-    if (c.fuse_tails) {
+    if (rs) {
+        LSA_REQUIRE(c.fuse_tails && level >= 1 && base && base_polys == 2, "merged ModDown+rescale: unsupported shape");
+        const int l = level;
+        // t[h] = (INTT(acc[h][l]) - conv[h][l]) * P^-1 + INTT(base[h][l]) -> p[h][l].  base is the caller's scratch here
+        // (the tensor output): its last limbs are transformed in place, nothing reads them in NTT form afterwards.
+        u64* base_rw = const_cast<u64*>(base);
+        RowMap rb;
+        rb.period = 1;
+        rb.mod_of[0] = (unsigned char)l;
+        rb.row0 = l;
+        rb.row_step = base_rpp;
+        launch_ntt(c, base_rw, base_rw, nb, sbase, sbase, 2, rb, true, s);
+        const unsigned char lm[1] = {(unsigned char)l};
+        launch_sub_mul_general(c, 2, 1, lm, c.pinv_vec(level) + l, acc + (long long)l * N, s_acc, T, conv + (long long)l * N,
+                               s_conv, L, base + (long long)l * N, sbase, base_rpp, 2, p + (long long)l * N, sp, L, nb, s);
+        // every other limb: in = conv_j*P^-1 + lift_j(t), out = (acc_j*P^-1 - NTT(in) + base_j) * q_l^-1
+        RowMap rmo;
+        rmo.period = 2 * L;
+        for (int h = 0; h < 2; h++)
+            for (int j = 0; j < L; j++) rmo.mod_of[h * L + j] = j == l ? LSA_ROW_SKIP : (unsigned char)j;
+        NttFusion fb;
+        fb.pro = 2;
+        fb.epi = 2;
+        fb.limbs = L;
+        fb.ql_mod = l;
+        fb.last = p + (long long)l * N;
+        fb.last_stride = sp;
+        fb.last_rpp = L;
+        fb.a = acc;
+        fb.a_stride = s_acc;
+        fb.a_rpp = T;
+        fb.base = base;
+        fb.base_stride = sbase;
+        fb.base_rpp = base_rpp;
+        fb.base_polys = base_polys;
+        fb.k = c.pinv_vec(level);
+        fb.k2 = c.qlinv_vec(level);
+        fb.out = rs->out;
+        fb.out_stride = rs->sout;
+        fb.out_rpp = level;
+        launch_ntt(c, conv, conv, nb, s_conv, s_conv, 2 * L, rmo, false, s, &fb);
+    } else if (c.fuse_tails) {
         // forward NTT of conv with the ModDown tail fused into its last-pass store: the transformed conv is consumed in
         // registers ((acc_Q - conv) * P^-1 + base) and never written
         NttFusion fz;
@@ -258,6 +314,11 @@ void ckks_mult_relin_rescale(Context& c, int level, const u64* a, const u64* b, 
         u64* r2 = d3 + r_d3 * N * tb;
         u64* sub = r2 + r_r2 * N * tb;
         launch_tensor(c, a + (size_t)b0 * sa, b + (size_t)b0 * sb, d3, nb, sa, sb, sd, L, rm_seq(L), st);
+        if (c.fuse_tails) {
+            const KsRescale rs{out + (size_t)b0 * so, so};
+            key_switch(c, level, d3 + 2LL * L * N, sd, rlk, r2, sr, d3, sd, L, 2, nb, sub, st, &rs);
+            return;
+        }
         key_switch(c, level, d3 + 2LL * L * N, sd, rlk, r2, sr, d3, sd, L, 2, nb, sub, st);
         rescale(c, level, 2, r2, sr, out + (size_t)b0 * so, so, nb, true, sub, st);
     });
