@@ -35,7 +35,7 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
         for (long long bid = 0; bid < nblocks; bid++) {
             NttBlockCtx bc = ntt_decode_block(a, bid);
             if (bc.mod == LSA_ROW_SKIP) continue;
-            for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_load(a, bc, t, lds.data());
+            for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_load<true>(a, bc, t, lds.data());
             int np = (a.mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO, base = a.mu / np, extra = a.mu % np;
             if (!inverse) {
                 int sig = 0;
@@ -52,7 +52,7 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
                     for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_sub_dyn(a, bc, t, lds.data(), sig, rho);
                 }
             }
-            for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_store(a, bc, t, lds.data());
+            for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_store<true>(a, bc, t, lds.data());
         }
     }
     return 0;

@@ -46,6 +46,8 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
     }
 }
 
+// FZ: the launch carries a fused prologue/epilogue (NttPassArgs::fz_*)
+template <bool FZ>
 __global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
@@ -70,16 +72,16 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(Ntt
     return;
 #endif
     LSA_STAMP(0);
-    ntt_phase_load(a, bc, tid, lds);
+    ntt_phase_load<FZ>(a, bc, tid, lds);
     LSA_STAMP(1);
     __syncthreads();
     LSA_STAMP(2);
 #if defined(LSA_NTT_DIAG_COPY_ONLY)   // diagnostic build: data movement of the pass structure without butterflies
-    ntt_phase_store(a, bc, tid, lds);
+    ntt_phase_store<FZ>(a, bc, tid, lds);
     return;
 #endif
     ntt_butterfly_phases(a, bc, tid, lds);
-    ntt_phase_store(a, bc, tid, lds);
+    ntt_phase_store<FZ>(a, bc, tid, lds);
     LSA_STAMP(7);
 #else
     // software-pipelined walk over consecutive tiles (same limb and tile index, different batch items: same twiddles)
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(Ntt
         if (have_nxt) ntt_phase_fetch(a, nxt, tid, stage);   // in flight during the butterflies below
         if (have) {
             ntt_butterfly_phases(a, bc, tid, lds);
-            ntt_phase_store(a, bc, tid, lds);
+            ntt_phase_store<FZ>(a, bc, tid, lds);
         }
         __syncthreads();   // LDS is reused by the next tile
     }
@@ -186,7 +188,8 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
             const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
             // one launch = one pass = 1/npass of the limb transforms it touches (algorithmic 16*N bytes per transform)
             ProfScope ps(c, PROF_NTT, 16.0 * c.n * active_rows * nb / c.plan.npass, s);
-            hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
+            if (fz) hipLaunchKernelGGL(k_ntt_pass<true>, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
+            else hipLaunchKernelGGL(k_ntt_pass<false>, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
             LSA_HIP(hipGetLastError());
         }
     }

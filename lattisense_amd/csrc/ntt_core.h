@@ -195,12 +195,14 @@ LSA_HD u64 ntt_load_fix(const NttLoadFix& f, u64 v, u64 t) {
     if (f.fp) v = d_to_bits(u52_to_double(v));  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact
     return v;
 }
+// FZ = false compiles the fused prologue out (plain launches: fewer live constants, smaller code)
+template <bool FZ>
 LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     const u64* g = a.src + bc.base_src;
     const u64* gl = g;   // last-limb source of the head modes
     const int half = 1 << (a.tau - 1);
     NttLoadFix f;
-    f.head = a.fz_pro && a.s_lo == 0;   // fused rescale head: the tile is derived from the (coefficient-domain) last limb
+    f.head = FZ && a.fz_pro && a.s_lo == 0;   // fused rescale head: the tile is derived from the (coefficient-domain) last limb
     f.add = f.head && a.fz_pro == 2;
     f.fp = bc.fp != 0;
     f.mi = a.mods[bc.mod];
@@ -347,6 +349,7 @@ LSA_HD void ntt_store_pair(u64* gp, u64 v0, u64 v1) {
     gp[1] = v1;
 #endif
 }
+template <bool FZ>
 LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64* lds) {
     u64* g = a.dst + bc.base_dst;
     const ModDev md = a.mods[bc.mod];
@@ -354,7 +357,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     NttStoreFix f;
     f.fp = bc.fp != 0;
     f.final_reduce = a.final_reduce != 0;
-    f.tail = a.fz_epi && a.final_reduce;
+    f.tail = FZ && a.fz_epi && a.final_reduce;
     f.q = md.q;
     f.qinv = md.qinv;
     f.qd = (double)md.q;
