@@ -316,16 +316,21 @@ LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 struct NttStoreFix {   // per-block constants of the store-side conversions
     bool fp, final_reduce, tail, with_base, merged;
     u64 q, qinv, k, k2;
-    double qd, qinvd;
+    double qd, qinvd, kd, k2d;   // kd/k2d: the tail factors as plain doubles (FP64-engine limbs)
 };
 LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
-    if (f.fp) {  // always canonical on store: the next pass reloads exact small integers
-        double r = fp_reduce(d_from_bits(v), f.qd, f.qinvd);
-        if (r < 0) r += f.qd;   // |r| <= q/2 (+ rounding slack): one conditional add lands in [0, q)
-        v = double_to_u52(r);
-    } else if (f.final_reduce) {
-        v = csub(csub(v, 2 * f.q), f.q);
+    if (f.fp) {
+        double r = fp_reduce(d_from_bits(v), f.qd, f.qinvd);   // |r| <= q/2 (+ rounding slack)
+        if (f.tail) {   // the fused tail of an FP64-engine limb stays on the FP64 engine: exact, 6 operations per product
+            const double ad = u52_to_double(va), bd = f.with_base ? u52_to_double(vb) : 0.0;
+            if (f.merged) r = fp_modmul(fp_modmul(ad, f.kd, f.qd, f.qinvd) - r + bd, f.k2d, f.qd, f.qinvd);
+            else r = fp_modmul(ad - r, f.kd, f.qd, f.qinvd) + bd;
+            r = fp_reduce(r, f.qd, f.qinvd);
+        }
+        if (r < 0) r += f.qd;   // one conditional add lands in [0, q): canonical on store
+        return double_to_u52(r);
     }
+    if (f.final_reduce) v = csub(csub(v, 2 * f.q), f.q);
     if (f.tail) {   // fused tail: the transformed value is consumed here and never stored
         if (f.merged) {
             v = sub_mod(mont_mul(va, f.k, f.q, f.qinv), v, f.q);
@@ -363,6 +368,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     f.qd = (double)md.q;
     f.qinvd = 1.0 / f.qd;
     f.k = f.k2 = 0;
+    f.kd = f.k2d = 0.0;
     f.merged = false;
     const int poly = f.tail ? bc.row / a.fz_limbs : 0, limb = f.tail ? bc.row % a.fz_limbs : 0;
     f.with_base = f.tail && a.fz_base && poly < a.fz_base_polys;
@@ -373,6 +379,10 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         f.k = a.fz_k[limb];
         f.merged = a.fz_epi == 2;
         if (f.merged) f.k2 = a.fz_k2[limb];
+        if (f.fp) {   // Montgomery form -> plain value (k*R * 1 * R^-1), exact as a double below 2^47
+            f.kd = (double)mont_mul(f.k, 1, f.q, f.qinv);
+            f.k2d = f.merged ? (double)mont_mul(f.k2, 1, f.q, f.qinv) : 0.0;
+        }
         g = a.fz_out + (long long)bc.b * a.fz_out_stride + (((long long)poly * a.fz_out_rpp + limb) << a.logn);
         if (f.with_base) pb = a.fz_base + (long long)bc.b * a.fz_base_stride + (((long long)poly * a.fz_base_rpp + limb) << a.logn);
     }
