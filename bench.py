@@ -33,8 +33,8 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep", "deep17", "task_ckks", "task_bfv"])
     ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU (0 = workload default)")
     ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--dual-stream", action="store_true", help="overlap alternate tiles on an auxiliary stream (A/B)")
     ap.add_argument("--no-fuse", action="store_true", help="separate ModDown/rescale tail kernels (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-stride", type=int, default=5)
+    ap.add_argument("--prof-stride", type=int, default=4)
     return ap.parse_args()
 
 
