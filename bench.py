@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep", "deep17", "task_ckks", "task_bfv"])
+    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep", "deep17", "task_ckks", "task_bfv", "task_conv"])
     ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU (0 = workload default)")
     ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
     ap.add_argument("--ntt-chunk-mib", type=int, default=-1, help="Infinity-Cache chunk of two-pass NTTs (-1 = default)")
@@ -124,8 +124,63 @@ def run_task_workload(args):
         "roofline": None, "cpu_baseline": None}), flush=True)
 
 
+def run_conv_workload(args):
+    """The reference's application benchmark shape (examples/benchmark_convolution, config 4 in / 4 out channels of 32x32,
+    3x3 kernel, CKKS N=16384 at level 2) end-to-end through run_fhe_gpu_task with host buffers: 71 rotations (NAF-shared),
+    72 ct x pt products, a 72-term accumulation, rescale, bias.  Arguments are built from the task signature."""
+    import numpy as np
+    from lattisense_amd.task import Argument, Ciphertext, FheTaskGpu, GaloisKey, KeySwitchKey, Plaintext
+    name = "ckks_n16384_conv2d_4in_4out_32x32_3x3"
+    path = os.path.join(ROOT, "tests", "golden", "tasks_bench", name)
+    g = json.load(open(os.path.join(path, "mega_ag.json")))
+    sig = json.load(open(os.path.join(path, "task_signature.json")))
+    P = g["parameter"]
+    n, q, p = P["n"], P["q"][: P["max_level"] + 1], P["p"]
+    rng = np.random.default_rng(0)
+
+    def rand(shape_prefix, mods):
+        out = np.empty((*shape_prefix, len(mods), n), dtype=np.uint64)
+        for i, m in enumerate(mods):
+            out[..., i, :] = rng.integers(0, m, size=(*shape_prefix, n), dtype=np.uint64)
+        return out
+
+    ins, outs = [], []
+    for a in sig["online"]:
+        count = int(np.prod(a["size"]))
+        lvl = a["level"]
+        if a["phase"] == "out":
+            outs.append(Argument(a["id"], [Ciphertext.empty(1, lvl, n) for _ in range(count)]))
+        elif a["type"] == "ct":
+            ins.append(Argument(a["id"], [Ciphertext(rand((2,), q[: lvl + 1])) for _ in range(count)]))
+        else:
+            ins.append(Argument(a["id"], [Plaintext(rand((), q[: lvl + 1])) for _ in range(count)]))
+    keys = {}
+    for e, lvl in sig["key"]["glk"].items():
+        beta = (lvl + 1 + len(p) - 1) // len(p)
+        keys[int(e)] = KeySwitchKey(rand((beta, 2), q[: lvl + 1] + p), lvl, len(p))
+    ins.append(Argument("glk_ntt", [GaloisKey(keys)]))
+    t = FheTaskGpu(path)
+    for _ in range(args.warmup):
+        t.run(ins, outs)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t.run(ins, outs)
+    dt = time.perf_counter() - t0
+    st = t.last_run_stats()
+    print(json.dumps({
+        "metric": "conv2d_layer_end_to_end_rate", "value": args.steps / dt, "unit": "layers/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": name + " through run_fhe_gpu_task (host buffers, PCIe-inclusive)",
+                   "compute_nodes": len(g["compute"]), "gpu_nodes": st["gpu_nodes"],
+                   "batched_launch_groups": st["gpu_batches"]},
+        "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "task_conv":
+        return run_conv_workload(args)
     if args.workload.startswith("task_"):
         return run_task_workload(args)
     import torch

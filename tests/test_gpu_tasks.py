@@ -297,3 +297,48 @@ def test_ringt_plaintext_and_mac_tasks():
         exp = (exp + cmsg[i] * pmsg[i]) % tm
     assert np.array_equal(c.bfv_decrypt(z[0].data), exp)
     t.close()
+
+
+def test_ckks_conv2d_application_graph():
+    """Packed conv2d layer (graph shape of the reference's examples/benchmark_convolution): 17 NAF-shared rotations, 18
+    ct x pt products, an 18-term add chain, rescale, bias.  Every output bit-exact against the oracle walked node by node,
+    and the decrypted result against the same graph evaluated on the slot vectors."""
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, GaloisKey, KeySwitchKey, Plaintext
+    from oracle.client import mean_precision_bits
+    from tests.graph_oracle import eval_cipher, eval_plain
+    name = "ckks_n4096_conv2d_1in_1out_32x32_3x3"
+    g, P, o, c = _load(name)
+    sig = json.load(open(os.path.join(TASKS, name, "task_signature.json")))
+    n, lvl, scale = P["n"], 2, float(2 ** 34)
+    rng = np.random.default_rng(21)
+    data = g["data"]
+    cipher, plain, args = {}, {}, {"input_0": [], "convw": [], "convb": []}
+    out_scale = scale * scale / P["q"][lvl]
+    for idx in g["inputs"]:
+        d = data[str(idx)]
+        if d["type"] == "ct":
+            m = rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2)
+            cipher[idx], plain[idx] = c.ckks_encrypt(m, lvl, scale), (m, scale)
+            args["input_0"].append(Ciphertext(cipher[idx]))
+        elif d["type"] == "pt":
+            bias = d["id"].startswith("convb")
+            m = rng.uniform(-1, 1, n // 2) + 0j
+            s = out_scale if bias else scale
+            cipher[idx], plain[idx] = c.ckks_encode_ntt(m, d["level"], s), (m, s)
+            args["convb" if bias else "convw"].append(Plaintext(cipher[idx]))
+    elts = [int(e) for e in sig["key"]["glk"]]
+    keys = {e: c.gen_galois_key(e, lvl) for e in elts}
+    glk = GaloisKey({e: KeySwitchKey(k, lvl, len(P["p"])) for e, k in keys.items()})
+    t = _task(name)
+    out = [Ciphertext.empty(1, lvl - 1, n)]
+    t.run([Argument("input_0", args["input_0"]), Argument("convw", args["convw"]), Argument("convb", args["convb"]),
+           Argument("glk_ntt", [glk])], [Argument("output", out)])
+    st = t.last_run_stats()
+    assert st["gpu_nodes"] == len(g["compute"]) and st["gpu_batches"] < st["gpu_nodes"]
+    want = eval_cipher(g, o, cipher, keys)[g["outputs"][0]]
+    assert np.array_equal(out[0].data, want)
+    msg, s = eval_plain(g, plain, P["q"])[g["outputs"][0]]
+    re, im = mean_precision_bits(msg, c.ckks_decrypt(out[0].data, s))
+    assert re >= 10 and im >= 10
+    t.close()

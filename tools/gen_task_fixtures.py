@@ -144,6 +144,53 @@ def main():
     ys = [rotate_rows(xs[i], f"y_{i}") for i in range(N_OP)]
     emit("bfv_n4096_rotate_row", [Argument("xs", xs)], [Argument("ys", ys)])
 
+    # application-shaped graph: packed conv2d, 1 -> 1 channels of 32x32, 3x3 kernel (two channel slots per ciphertext at N=4096)
+    conv_fixture("ckks_n4096_conv2d_1in_1out_32x32_3x3", ckks_param(4096, 5), 4096, 1, 1, (32, 32), (3, 3), 2)
+
+
+def conv2d_graph(n, n_in, n_out, shape, kernel, level):
+    """The packed 2-D convolution layer of the reference's application benchmark, restated through the frontend API
+    (graph shape of examples/benchmark_convolution/benchmark_convolution.py:44-163, stride 1, skip 1): every packed
+    input ciphertext is rotated to each channel slot, each of those to every kernel offset (rows, then columns), each
+    rotated copy is multiplied by its weight plaintext and accumulated, then one rescale and a bias plaintext."""
+    h, w = shape
+    kh, kw = kernel
+    per_ct = (n // 2) // (h * w)                      # channels packed in one ciphertext
+    pin, pout = -(-n_in // per_ct), -(-n_out // per_ct)
+    xs = [CkksCiphertextNode(f"input_0_{i}", level=level) for i in range(pin)]
+    wts = [[[CkksPlaintextNode(f"convw_{o}_{c}_{k}", level) for k in range(kh * kw)] for c in range(pin * per_ct)]
+           for o in range(pout)]
+    bias = [CkksPlaintextNode(f"convb_{o}", level - 1) for o in range(pout)]
+
+    def both_sides(x, reach, unit):                   # [x rotated by -reach*unit, ..., x, ..., +reach*unit]
+        if reach == 0:
+            return [x]
+        steps = [-i * unit for i in range(1, reach + 1)] + [i * unit for i in range(1, reach + 1)]
+        r = rotate_cols(x, steps)
+        return list(reversed(r[:reach])) + [x] + r[reach:]
+
+    chans = []
+    for x in xs:                                      # channel slots of each packed input
+        chans.append(x)
+        if per_ct > 1:
+            chans += rotate_cols(x, [i * h * w for i in range(1, per_ct)])
+    taps = [[t for r in both_sides(c, kw // 2, w) for t in both_sides(r, kh // 2, 1)] for c in chans]
+    outs = []
+    for o in range(pout):
+        acc = None
+        for c in range(pin * per_ct):
+            for k in range(kh * kw):
+                prod = mult(taps[c][k], wts[o][c][k])
+                acc = prod if acc is None else add(acc, prod)
+        outs.append(add(rescale(acc), bias[o]))
+    return xs, wts, bias, outs
+
+
+def conv_fixture(name, param, n, n_in, n_out, shape, kernel, level):
+    set_fhe_param(param)
+    xs, wts, bias, outs = conv2d_graph(n, n_in, n_out, shape, kernel, level)
+    emit(name, [Argument("input_0", xs), Argument("convw", wts), Argument("convb", bias)], [Argument("output", outs)])
+
 
 def bench_fixtures():
     """Benchmark-shaped graphs (examples/benchmark_gpu/benchmark_gpu.py:25-58: n_op disjoint mult_relin subgraphs),
@@ -164,6 +211,9 @@ def bench_fixtures():
     ys = [BfvCiphertextNode(f"y_{i}", level=lv) for i in range(n_op)]
     zs = [mult_relin(xs[i], ys[i], f"z_{i}") for i in range(n_op)]
     emit("bfv_n16384_l3_cmc_relin_x256", [Argument("xs", xs), Argument("ys", ys)], [Argument("zs", zs)])
+    # examples/benchmark_convolution config (4, 4, (32,32), (3,3)) on the default CKKS N=16384 chain, init level 2
+    conv_fixture("ckks_n16384_conv2d_4in_4out_32x32_3x3", CkksParam.create_default_param(16384), 16384, 4, 4, (32, 32),
+                 (3, 3), 2)
 
 
 if __name__ == "__main__":
