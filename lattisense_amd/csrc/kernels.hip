@@ -293,6 +293,84 @@ void launch_muladd(Context& c, EwOp op, const u64* a, const u64* b, const u64* a
     LSA_HIP(hipGetLastError());
 }
 
+// ciphertext x plaintext multiply-accumulate over up to LSA_MAC_MAX_TERMS terms in ONE launch (cmp_sum / cmpac_sum nodes,
+// mega_ag_executors_gpu.cu:294-408 does multiply_plain + add_inplace per term):
+//   out[p][j] = (partial[p][j]) + sum_i ct_i[p][j] * pt_i[j]
+// The products are summed as 128-bit integers and reduced once (REDC, then * R^2), folded every 8 terms.
+struct MacPlainArgs {
+    const u64* ct[LSA_MAC_MAX_TERMS];
+    const u64* pt[LSA_MAC_MAX_TERMS];
+    long long sct[LSA_MAC_MAX_TERMS], spt[LSA_MAC_MAX_TERMS];
+    const u64* partial;
+    u64* out;
+    long long spartial, so;
+    const ModDev* mods;
+    int terms, polys, limbs, logn;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+
+// grid: x = polys*limbs*(N/2/TPB), y = batch
+__global__ __launch_bounds__(TPB) void k_mac_plain(MacPlainArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;             // poly * limbs + limb
+    const int limb = row % g.limbs;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const ModDev m = g.mods[g.mod_of[limb]];
+    const long long b = blockIdx.y;
+    const long long coff = ((long long)row << g.logn) + x, poff = ((long long)limb << g.logn) + x;
+    u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0, r0 = 0, r1 = 0;
+    for (int i = 0; i < g.terms; i++) {
+        const ulonglong2 c = ld2(g.ct[i] + b * g.sct[i] + coff);
+        const ulonglong2 w = ld2(g.pt[i] + b * g.spt[i] + poff);
+        mac128(h0, l0, c.x, w.x);
+        mac128(h1, l1, c.y, w.y);
+        if ((i & 7) == 7) {   // keep the 128-bit sum below q*2^64 (8 products of < q^2, q < 2^61)
+            r0 = add_mod(r0, csub(mont_redc_lazy(h0, l0, m.q, m.qinv), m.q), m.q);
+            r1 = add_mod(r1, csub(mont_redc_lazy(h1, l1, m.q, m.qinv), m.q), m.q);
+            h0 = l0 = h1 = l1 = 0;
+        }
+    }
+    r0 = add_mod(r0, csub(mont_redc_lazy(h0, l0, m.q, m.qinv), m.q), m.q);
+    r1 = add_mod(r1, csub(mont_redc_lazy(h1, l1, m.q, m.qinv), m.q), m.q);
+    r0 = mont_mul(r0, m.r2, m.q, m.qinv);            // sum * R^-1 -> sum
+    r1 = mont_mul(r1, m.r2, m.q, m.qinv);
+    if (g.partial) {
+        const ulonglong2 v = ld2(g.partial + b * g.spartial + coff);
+        r0 = add_mod(r0, v.x, m.q);
+        r1 = add_mod(r1, v.y, m.q);
+    }
+    st2(g.out + b * g.so + coff, r0, r1);
+}
+
+void launch_mac_plain(Context& c, int terms, const u64* const* ct, const long long* sct, const u64* const* pt,
+                      const long long* spt, const u64* partial, long long spartial, u64* out, long long so, int batch,
+                      int polys, int limbs, const RowMap& rm, hipStream_t s) {
+    if (batch <= 0 || terms <= 0) return;
+    LSA_REQUIRE(terms <= LSA_MAC_MAX_TERMS, "too many terms for one multiply-accumulate launch");
+    LSA_REQUIRE(rm.period == limbs && limbs <= LSA_MAX_PERIOD, "mac: row map must cover the limbs");
+    MacPlainArgs g{};
+    for (int i = 0; i < terms; i++) {
+        g.ct[i] = ct[i];
+        g.sct[i] = sct[i];
+        g.pt[i] = pt[i];
+        g.spt[i] = spt[i];
+    }
+    g.partial = partial;
+    g.spartial = spartial;
+    g.out = out;
+    g.so = so;
+    g.mods = c.d_mods;
+    g.terms = terms;
+    g.polys = polys;
+    g.limbs = limbs;
+    g.logn = c.logn;
+    int period;
+    fill_rowmap(g.mod_of, period, rm, c.nmod);
+    ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * limbs * batch * ((double)terms * (polys + 1) + polys * (partial ? 2 : 1)), s);
+    hipLaunchKernelGGL(k_mac_plain, ew_grid(c, polys * limbs, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
 // tensor product of two degree-1 ciphertexts: d0=a0*b0, d1=a0*b1+a1*b0, d2=a1*b1 (mega_ag_executors_gpu.cu:185,223)
 struct TensorArgs {
     const u64* a;

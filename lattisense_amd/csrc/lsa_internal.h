@@ -204,6 +204,11 @@ void launch_elementwise(Context& c, EwOp op, const u64* a, const u64* b, u64* ou
                         long long sb, long long so, int rows, const RowMap& rm, hipStream_t s);
 void launch_muladd(Context& c, EwOp op, const u64* a, const u64* b, const u64* acc, long long sacc, u64* out, int batch,
                    long long sa, long long sb, long long so, int rows, const RowMap& rm, hipStream_t s);
+// out[p][j] = (partial[p][j]) + sum_{i<terms} ct_i[p][j] * pt_i[j], one launch; each operand is (base, batch stride)
+#define LSA_MAC_MAX_TERMS 16
+void launch_mac_plain(Context& c, int terms, const u64* const* ct, const long long* sct, const u64* const* pt,
+                      const long long* spt, const u64* partial, long long spartial, u64* out, long long so, int batch,
+                      int polys, int limbs, const RowMap& rm, hipStream_t s);
 // ring-t plaintext limb -> [level+1][N] residues: mode 0 centred lift from q_0 (CKKS), 1 direct (BFV multiply),
 // 2 scale-up by Q/t (BFV add/sub)
 void launch_lift_ringt(Context& c, int mode, int level, const u64* pt, long long spt, u64* out, long long sout, int batch,

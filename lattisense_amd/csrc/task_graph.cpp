@@ -4,6 +4,7 @@
 #include "task_graph.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <queue>
 #include <stdexcept>
 
@@ -46,6 +47,7 @@ bool is_custom_json(const mjson::Value& v) { return v.contains("is_custom") && v
 TaskGraph TaskGraph::load_for_gpu(const std::string& json_path) {
     TaskGraph g;
     g.parse(json_path);
+    if (!getenv("LSA_NO_GRAPH_FUSION")) g.fuse_accumulations();
     g.insert_bridges();
     g.assign_processors();
     g.compute_levels();
@@ -140,6 +142,110 @@ void TaskGraph::parse(const std::string& json_path) {
     for (auto& e : root["outputs"].arr) {
         outputs.push_back(e.as_u64());
         data.at(e.as_u64()).is_output = true;
+    }
+}
+
+// Peephole: a tree of `add` nodes whose leaves are single-use ciphertext x plaintext products (the shape the frontend
+// emits for convolutions and matrix-vector products, e.g. examples/benchmark_convolution: mult(ct,pt) + add chains) is
+// rewritten into the graph's own multiply-accumulate nodes (cmp_sum / cmpac_sum, <= 16 terms each, chained through the
+// partial-sum input).  Modular addition is associative and commutative, so every residue of the result is unchanged; a
+// 72-term accumulation becomes 5 launches instead of 72 products + 71 dependent additions.
+void TaskGraph::fuse_accumulations() {
+    auto is_ct = [](const DatumNode* d) { return d->datum_type == TYPE_CIPHERTEXT && d->fhe_prop && d->fhe_prop->degree == 1; };
+    auto is_pt = [](const DatumNode* d) { return d->datum_type == TYPE_PLAINTEXT && d->fhe_prop; };
+    auto sole_producer = [](const DatumNode* d) -> ComputeNode* {
+        return (d->predecessors.size() == 1 && d->successors.size() == 1 && !d->is_output && !d->is_input) ? d->predecessors[0]
+                                                                                                              : nullptr;
+    };
+    auto is_product = [&](const ComputeNode* c) {
+        return c && c->op() == OperationType::MULTIPLY && c->input_nodes.size() == 2 && is_ct(c->input_nodes[0]) &&
+               is_pt(c->input_nodes[1]) && c->output_nodes.size() == 1;
+    };
+    auto is_add = [&](const ComputeNode* c) {
+        return c && c->op() == OperationType::ADD && c->input_nodes.size() == 2 && is_ct(c->input_nodes[0]) &&
+               is_ct(c->input_nodes[1]) && c->output_nodes.size() == 1;
+    };
+    std::vector<NodeIndex> roots;
+    for (auto& kv : computes) {
+        ComputeNode* c = &kv.second;
+        if (!is_add(c)) continue;
+        DatumNode* out = c->output_nodes[0];
+        ComputeNode* user = (out->successors.size() == 1 && !out->is_output) ? out->successors[0] : nullptr;
+        if (!is_add(user)) roots.push_back(kv.first);   // the top of a tree
+    }
+    std::sort(roots.begin(), roots.end());
+    for (NodeIndex ri : roots) {
+        ComputeNode* root = &computes.at(ri);
+        const int level = root->output_nodes[0]->fhe_prop->level;
+        std::vector<ComputeNode*> adds{root}, prods;
+        std::vector<DatumNode*> others;   // operands that are neither an inner add nor a product
+        for (size_t i = 0; i < adds.size(); i++)
+            for (DatumNode* in : adds[i]->input_nodes) {
+                ComputeNode* p = sole_producer(in);
+                if (in->fhe_prop->level != level) p = nullptr;
+                if (is_add(p)) adds.push_back(p);
+                else if (is_product(p) && p->input_nodes[0]->fhe_prop->level == level &&
+                         p->input_nodes[1]->fhe_prop->level == level)
+                    prods.push_back(p);
+                else others.push_back(in);
+            }
+        if (prods.size() < 2 || others.size() > 1) continue;   // nothing to gain / more than one partial sum
+        std::sort(prods.begin(), prods.end(), [](ComputeNode* a, ComputeNode* b) { return a->index < b->index; });
+        DatumNode* final_out = root->output_nodes[0];
+        DatumNode* partial = others.empty() ? nullptr : others[0];
+        // detach everything that disappears
+        auto unlink = [&](ComputeNode* c) {
+            for (DatumNode* in : c->input_nodes) {
+                auto& v = in->successors;
+                v.erase(std::remove(v.begin(), v.end(), c), v.end());
+            }
+            for (DatumNode* o : c->output_nodes) {
+                auto& v = o->predecessors;
+                v.erase(std::remove(v.begin(), v.end(), c), v.end());
+            }
+        };
+        std::vector<DatumNode*> cts, pts;
+        for (ComputeNode* p : prods) {
+            cts.push_back(p->input_nodes[0]);
+            pts.push_back(p->input_nodes[1]);
+        }
+        std::vector<NodeIndex> dead_compute, dead_data;
+        for (ComputeNode* p : prods) {
+            dead_data.push_back(p->output_nodes[0]->index);
+            dead_compute.push_back(p->index);
+            unlink(p);
+        }
+        for (ComputeNode* a : adds) {
+            if (a != root) dead_data.push_back(a->output_nodes[0]->index);
+            dead_compute.push_back(a->index);
+            unlink(a);
+        }
+        for (NodeIndex d : dead_data) data.erase(d);
+        for (NodeIndex c : dead_compute) computes.erase(c);
+        // chain of multiply-accumulate nodes
+        const size_t kmax = 16;
+        for (size_t i0 = 0; i0 < cts.size(); i0 += kmax) {
+            const size_t cnt = std::min(kmax, cts.size() - i0);
+            const bool last = i0 + cnt == cts.size();
+            DatumNode* out = last ? final_out : &clone_datum(*final_out, final_out->id + "_mac" + std::to_string(i0));
+            ComputeNode c;
+            c.index = next_compute++;
+            c.id = final_out->id + "_fused_mac" + std::to_string(i0);
+            ComputeNode::FheProperty fp;
+            fp.op_type = partial ? OperationType::MAC_W_PARTIAL_SUM : OperationType::MAC_WO_PARTIAL_SUM;
+            ComputeNode::FheProperty::ExtraProperty ep;
+            ep.sum_cnt = (int32_t)cnt;
+            fp.p = ep;
+            c.fhe_prop = fp;
+            for (size_t i = 0; i < cnt; i++) c.input_nodes.push_back(cts[i0 + i]);
+            if (partial) c.input_nodes.push_back(partial);
+            for (size_t i = 0; i < cnt; i++) c.input_nodes.push_back(pts[i0 + i]);
+            c.output_nodes.push_back(out);
+            auto it = computes.emplace(c.index, std::move(c)).first;
+            for (DatumNode* in : it->second.input_nodes) in->successors.push_back(&it->second);
+            out->predecessors.push_back(&it->second);
+            partial = out;
+        }
     }
 }
 

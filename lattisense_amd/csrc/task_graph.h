@@ -136,6 +136,7 @@ struct TaskGraph {
 
 private:
     void parse(const std::string& json_path);
+    void fuse_accumulations();
     void insert_bridges();
     void link_bridge(OperationType op, const std::string& id, DatumNode* in, DatumNode* out);
     void assign_processors();

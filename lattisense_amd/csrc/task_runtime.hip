@@ -393,12 +393,17 @@ struct fhe_task_handle_st {
                         dst += N;
                     }
         }
-        parallel_for(jobs.size(), [&](size_t i) { memcpy(jobs[i].dst, jobs[i].src, sizeof(u64) * N); });
+        // device destinations first (one slab per group / key), as segments of the staging order
+        struct Seg {
+            size_t off, words;
+            u64* dev;
+        };
+        std::vector<Seg> segs;
         for (auto& kv : groups) {
             auto& items = kv.second;
             const size_t per = (size_t)items[0].polys * (items[0].level + 1) * N;
             auto slab = dslab(per * items.size());
-            LSA_HIP(hipMemcpyAsync(slab->ptr, host + items[0].off, per * items.size() * sizeof(u64), hipMemcpyHostToDevice, s));
+            segs.push_back({items[0].off, per * items.size(), slab->ptr});
             for (size_t i = 0; i < items.size(); i++) {
                 auto d = std::make_shared<DevDatum>();
                 d->slab = slab;
@@ -409,11 +414,30 @@ struct fhe_task_handle_st {
                 avail[items[i].node->output_nodes[0]->index] = d;
             }
         }
+        std::vector<std::shared_ptr<DevKey>> dkeys;
         for (auto& k : keys) {
             const size_t words = (size_t)k.beta * 2 * k.comp * N;
             auto dk = std::make_shared<DevKey>();
             dk->slab = dslab(words);
-            LSA_HIP(hipMemcpyAsync(dk->slab->ptr, host + k.off, words * sizeof(u64), hipMemcpyHostToDevice, s));
+            segs.push_back({k.off, words, dk->slab->ptr});
+            dkeys.push_back(dk);
+        }
+        // gather and copy in chunks: while the DMA engine moves chunk k, the host threads gather chunk k+1 (the staging
+        // slab holds the whole level, so no chunk waits for a buffer)
+        const size_t chunk_jobs = std::max<size_t>(1, (32u << 20) / (sizeof(u64) * (size_t)N));
+        for (size_t j0 = 0; j0 < jobs.size(); j0 += chunk_jobs) {
+            const size_t j1 = std::min(jobs.size(), j0 + chunk_jobs);
+            parallel_for(j1 - j0, [&](size_t i) { memcpy(jobs[j0 + i].dst, jobs[j0 + i].src, sizeof(u64) * N); });
+            const size_t h0 = j0 * (size_t)N, h1 = j1 * (size_t)N;   // jobs are in staging order, one limb each
+            for (const Seg& sg : segs) {
+                const size_t a = std::max(h0, sg.off), b = std::min(h1, sg.off + sg.words);
+                if (a < b)
+                    LSA_HIP(hipMemcpyAsync(sg.dev + (a - sg.off), host + a, (b - a) * sizeof(u64), hipMemcpyHostToDevice, s));
+            }
+        }
+        for (size_t i = 0; i < keys.size(); i++) {
+            auto& k = keys[i];
+            auto& dk = dkeys[i];
             dk->key.data = dk->slab->ptr;
             dk->key.level = k.level;
             dk->key.owned = false;
@@ -650,7 +674,29 @@ struct fhe_task_handle_st {
                 const int pt0 = n + (with_partial ? 1 : 0);
                 LSA_REQUIRE((int)n0->input_nodes.size() == pt0 + n, "MAC node: unexpected number of inputs");
                 const int rows = polys_in * L;
-                u64* tmp = bfv ? temp((size_t)m * w_in) : nullptr;
+                if (!bfv) {   // CKKS: every operand is in the NTT domain already -> groups of <= 16 terms per launch
+                    Operand part{nullptr, 0, nullptr};
+                    if (with_partial) part = gather(c, s, nodes, n, avail, w_in);
+                    for (int i0 = 0; i0 < n; i0 += LSA_MAC_MAX_TERMS) {
+                        const int cnt = std::min(LSA_MAC_MAX_TERMS, n - i0);
+                        const u64* cp[LSA_MAC_MAX_TERMS];
+                        const u64* pp[LSA_MAC_MAX_TERMS];
+                        long long cs_[LSA_MAC_MAX_TERMS], ps_[LSA_MAC_MAX_TERMS];
+                        for (int i = 0; i < cnt; i++) {
+                            Operand ci = i0 + i == 0 ? a : gather(c, s, nodes, i0 + i, avail, w_in);
+                            Operand pi = plain_operand(pt0 + i0 + i, 0, true);
+                            cp[i] = ci.ptr;
+                            cs_[i] = ci.stride;
+                            pp[i] = pi.ptr;
+                            ps_[i] = pi.stride;
+                        }
+                        // the first group adds the node's partial sum, later groups continue from `out`
+                        const u64* acc = i0 == 0 ? part.ptr : out;
+                        launch_mac_plain(c, cnt, cp, cs_, pp, ps_, acc, i0 == 0 ? part.stride : so, out, so, m, polys_in, L, rmL, s);
+                    }
+                    break;
+                }
+                u64* tmp = temp((size_t)m * w_in);
                 std::vector<int> all(rows);
                 for (int i = 0; i < rows; i++) all[i] = i;
                 for (int i = 0; i < n; i++) {

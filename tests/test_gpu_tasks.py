@@ -330,13 +330,26 @@ def test_ckks_conv2d_application_graph():
     elts = [int(e) for e in sig["key"]["glk"]]
     keys = {e: c.gen_galois_key(e, lvl) for e in elts}
     glk = GaloisKey({e: KeySwitchKey(k, lvl, len(P["p"])) for e, k in keys.items()})
-    t = _task(name)
+    want = eval_cipher(g, o, cipher, keys)[g["outputs"][0]]
+    ins = [Argument("input_0", args["input_0"]), Argument("convw", args["convw"]), Argument("convb", args["convb"]),
+           Argument("glk_ntt", [glk])]
+    # as compiled (every mult / add its own node), then with the runtime's accumulation fusion (the 18 products and 17
+    # accumulating adds become two multiply-accumulate nodes of 16 + 2 terms): identical residues either way
+    os.environ["LSA_NO_GRAPH_FUSION"] = "1"
+    try:
+        t = _task(name)
+    finally:
+        del os.environ["LSA_NO_GRAPH_FUSION"]
     out = [Ciphertext.empty(1, lvl - 1, n)]
-    t.run([Argument("input_0", args["input_0"]), Argument("convw", args["convw"]), Argument("convb", args["convb"]),
-           Argument("glk_ntt", [glk])], [Argument("output", out)])
+    t.run(ins, [Argument("output", out)])
     st = t.last_run_stats()
     assert st["gpu_nodes"] == len(g["compute"]) and st["gpu_batches"] < st["gpu_nodes"]
-    want = eval_cipher(g, o, cipher, keys)[g["outputs"][0]]
+    assert np.array_equal(out[0].data, want)
+    t.close()
+    t = _task(name)
+    out = [Ciphertext.empty(1, lvl - 1, n)]
+    t.run(ins, [Argument("output", out)])
+    assert t.last_run_stats()["gpu_nodes"] == len(g["compute"]) - 18 - 17 + 2
     assert np.array_equal(out[0].data, want)
     msg, s = eval_plain(g, plain, P["q"])[g["outputs"][0]]
     re, im = mean_precision_bits(msg, c.ckks_decrypt(out[0].data, s))

@@ -25,10 +25,29 @@ def expected_counts(name):
 
 
 @pytest.mark.parametrize("name", sorted(d for d in os.listdir(TASKS) if "unsupported" not in d))
-def test_graph_loads_with_bridges(name):
+def test_graph_loads_with_bridges(name, monkeypatch):
     from lattisense_amd.task import FheTaskGpu
+    monkeypatch.setenv("LSA_NO_GRAPH_FUSION", "1")   # the graph exactly as compiled
     t = FheTaskGpu(os.path.join(TASKS, name))
     assert t.counts() == expected_counts(name)
+    t.close()
+
+
+def test_accumulation_fusion_rewrites_product_sums():
+    """mult(ct,pt) + add trees become the graph's own multiply-accumulate nodes (<= 16 terms each): the conv2d fixture's
+    18 products and 17 accumulating adds collapse into 2 nodes, one intermediate datum instead of 34."""
+    from lattisense_amd.task import FheTaskGpu
+    name = "ckks_n4096_conv2d_1in_1out_32x32_3x3"
+    want = expected_counts(name)
+    t = FheTaskGpu(os.path.join(TASKS, name))
+    got = t.counts()
+    assert got["compute"] == want["compute"] - 18 - 17 + 2
+    assert got["data"] == want["data"] - 18 - 16 + 1
+    assert got["inputs"] == want["inputs"] and got["outputs"] == want["outputs"]
+    t.close()
+    # graphs without such trees are untouched
+    t = FheTaskGpu(os.path.join(TASKS, "ckks_n4096_cmp_cap"))
+    assert t.counts() == expected_counts("ckks_n4096_cmp_cap")
     t.close()
 
 
