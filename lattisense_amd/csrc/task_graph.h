@@ -58,6 +58,7 @@ enum class OperationType {
     IMPORT_FROM_ABI,     // C struct       -> caller handle (caller's executor, CPU)
     LOAD_TO_BACKEND,     // C struct       -> device datum  (this library)
     STORE_FROM_BACKEND,  // device datum   -> C struct      (this library)
+    FUSED_MULT_RELIN_RESCALE,  // internal (never in a task file): mult -> relin -> rescale chain, inputs [a, (b,) rlk]
 };
 
 struct DatumNode {
@@ -137,6 +138,7 @@ struct TaskGraph {
 private:
     void parse(const std::string& json_path);
     void fuse_accumulations();
+    void fuse_mult_relin_rescale();
     void insert_bridges();
     void link_bridge(OperationType op, const std::string& id, DatumNode* in, DatumNode* out);
     void assign_processors();

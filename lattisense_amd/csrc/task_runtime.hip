@@ -28,6 +28,8 @@ namespace lsa {
 void ckks_relin(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
 void ckks_rescale(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
 void ckks_rotate(Context&, int, const u64*, u64, const Key&, u64*, int, long long, long long, hipStream_t);
+void ckks_mult_relin_rescale(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long, long long,
+                             hipStream_t);
 void bfv_mult(Context&, int, const u64*, const u64*, u64*, int, long long, long long, long long, hipStream_t);
 void bfv_relin(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
 void bfv_rotate(Context&, int, const u64*, u64, const Key&, u64*, int, long long, long long, hipStream_t);
@@ -179,6 +181,7 @@ const char* op_name(OperationType op) {
         case OperationType::MAC_WO_PARTIAL_SUM: return "cmp_sum";
         case OperationType::MAC_W_PARTIAL_SUM: return "cmpac_sum";
         case OperationType::BOOTSTRAP: return "bootstrap";
+        case OperationType::FUSED_MULT_RELIN_RESCALE: return "mult+relin+rescale";
         default: return "?";
     }
 }
@@ -212,6 +215,7 @@ void bind_gpu_executor(ComputeNode& node, Algo algorithm) {
         case OperationType::RELINEARIZE:
         case OperationType::RESCALE:
         case OperationType::ROTATE_ROW:
+        case OperationType::FUSED_MULT_RELIN_RESCALE:
             break;
         case OperationType::ROTATE_COL:
             if (!node.fhe_prop->p) throw std::runtime_error("Rotation step not found in FHE property");
@@ -558,7 +562,7 @@ struct fhe_task_handle_st {
         const size_t w_in = (size_t)polys_in * L * N;
         int out_polys = polys_in;
         if (op == OperationType::MULTIPLY && !(n0->input_nodes.size() == 2 && is_plain_node(n0->input_nodes[1]))) out_polys = 3;
-        if (op == OperationType::RELINEARIZE) out_polys = 2;
+        if (op == OperationType::RELINEARIZE || op == OperationType::FUSED_MULT_RELIN_RESCALE) out_polys = 2;
         const size_t w_out = (size_t)out_polys * (out_lvl + 1) * N;
         auto out_slab = dslab(w_out * m);
         u64* out = out_slab->ptr;
@@ -635,6 +639,13 @@ struct fhe_task_handle_st {
                 LSA_REQUIRE(polys_in == 2, "ciphertext multiply expects degree-1 operands");
                 if (bfv) bfv_mult(c, lvl, a.ptr, b.ptr, out, m, a.stride, b.stride, so, s);
                 else launch_tensor(c, a.ptr, b.ptr, out, m, a.stride, b.stride, so, L, rmL, s);
+                break;
+            }
+            case OperationType::FUSED_MULT_RELIN_RESCALE: {   // inputs [a, (b,) rlk]
+                LSA_REQUIRE(!bfv && polys_in == 2 && out_lvl == lvl - 1, "fused mult+relin+rescale: unexpected shape");
+                const int kpos = (int)n0->input_nodes.size() - 1;
+                Operand b = kpos == 1 ? a : gather(c, s, nodes, 1, avail, w_in);
+                ckks_mult_relin_rescale(c, lvl, a.ptr, b.ptr, key_of(kpos), out, m, a.stride, b.stride, so, s);
                 break;
             }
             case OperationType::RELINEARIZE:

@@ -44,7 +44,11 @@ def test_ckks_cmc_relin_rescale_task():
     xm, xs = _ckks_inputs(c, n, lvl, N_OP, 1)
     ym, ys = _ckks_inputs(c, n, lvl, N_OP, 2)
     rlk = c.gen_relin_key(lvl)
-    t = _task("ckks_n4096_cmc_relin_rescale")
+    os.environ["LSA_NO_GRAPH_FUSION"] = "1"       # first the graph exactly as compiled: three operator nodes per op
+    try:
+        t = _task("ckks_n4096_cmc_relin_rescale")
+    finally:
+        del os.environ["LSA_NO_GRAPH_FUSION"]
     zs = [Ciphertext.empty(1, lvl - 1, n) for _ in range(N_OP)]
     seen = []
     ns = t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
@@ -62,6 +66,16 @@ def test_ckks_cmc_relin_rescale_task():
     ns2 = t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
                  Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("out_z_list", zs)])
     assert ns2 > 0 and np.array_equal(zs[0].data, o.ckks_mult_relin_rescale(lvl, xs[0], ys[0], rlk, lvl))
+    t.close()
+    # default: the runtime fuses each mult -> relin -> rescale chain into one node (merged ModDown+rescale tail)
+    t = _task("ckks_n4096_cmc_relin_rescale")
+    zs = [Ciphertext.empty(1, lvl - 1, n) for _ in range(N_OP)]
+    t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
+           Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("out_z_list", zs)])
+    st = t.last_run_stats()
+    assert st["gpu_nodes"] == N_OP and st["gpu_batches"] == 1
+    for i in range(N_OP):
+        assert np.array_equal(zs[i].data, o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk, lvl))
     t.close()
 
 
