@@ -233,10 +233,11 @@ static void rescale(Context& c, int level, int polys, const u64* in, long long s
 // ------------------------------------------------------------------------------------------------ tiling
 static int pick_tile(const Context& c, size_t rows_per_ct, int batch) {
     if (c.tile_batch > 0) return std::min(c.tile_batch, batch);
-    // measured on MI355X (gpurun_out/tile_sweep.log): launches need >= ~2k workgroups each to fill 256 CUs, which at
-    // N=2^16 means ~16 ciphertexts per wave; beyond that nothing is gained and the workspace only grows.
+    // measured on MI355X (profiles/r01/tile_sweep*.log): launches need >= ~2k workgroups each to fill 256 CUs (~16
+    // ciphertexts per wave at N=2^16); past that the gain is the shrinking tail of each launch: +3 % (HMult) / +8 %
+    // (rotate) from 19 to 64 ciphertexts, for 6.6 GiB of workspace out of 288.
     const size_t bytes_per_ct = rows_per_ct * (size_t)c.n * sizeof(u64);
-    size_t tb = (2ull << 30) / std::max<size_t>(bytes_per_ct, 1);
+    size_t tb = (8ull << 30) / std::max<size_t>(bytes_per_ct, 1);
     if (tb < 1) tb = 1;
     if (tb > 64) tb = 64;
     return (int)std::min<size_t>(tb, (size_t)batch);
