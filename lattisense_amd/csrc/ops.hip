@@ -239,7 +239,9 @@ static int pick_tile(const Context& c, size_t rows_per_ct, int batch) {
     const size_t bytes_per_ct = rows_per_ct * (size_t)c.n * sizeof(u64);
     size_t tb = (8ull << 30) / std::max<size_t>(bytes_per_ct, 1);
     if (tb < 1) tb = 1;
-    if (tb > 64) tb = 64;
+    // the cap scales with 1/N (same work per launch): 64 at N=2^16, 256 at N=2^14 (BFV mult+relin +12 % over 64)
+    const size_t cap = std::min<size_t>(512, std::max<size_t>(64, (64ull << 16) / (size_t)c.n));
+    if (tb > cap) tb = cap;
     return (int)std::min<size_t>(tb, (size_t)batch);
 }
 
