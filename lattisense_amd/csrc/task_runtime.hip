@@ -15,11 +15,14 @@
 //   * every failure is turned into a non-zero return code + lsa_last_error(); nothing throws across extern "C".
 #include <atomic>
 #include <chrono>
+#include <functional>
+#include <optional>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <thread>
+#include <unordered_set>
 
 #include "lsa_internal.h"
 #include "task_graph.h"
@@ -261,14 +264,22 @@ void bind_gpu_executor(ComputeNode& node, Algo algorithm) {
 }
 
 struct fhe_task_handle_st {
-    BufPool dev_pool{false}, pin_pool{true};   // declared first: destroyed last (slabs below give their buffers back)
-    std::shared_ptr<Slab> dslab(size_t words) { return std::make_shared<Slab>(dev_pool, words); }
+    // Two execution lanes (stream + context + device-buffer pool each).  A run whose graph splits into independent
+    // subgraphs is pipelined over them: while lane A's chunk computes and copies its results back, lane B's chunk is
+    // staged and copied in (PCIe is full duplex; the reference's runner overlaps nothing across its 2 streams' copies).
+    // A released device buffer only returns to ITS lane's pool, so reuse stays ordered by that lane's in-order stream.
+    BufPool dev_pool0{false}, dev_pool1{false}, pin_pool{true};   // declared first: destroyed last
+    int cur_lane = 0;
+    std::shared_ptr<Slab> dslab(size_t words) { return std::make_shared<Slab>(cur_lane ? dev_pool1 : dev_pool0, words); }
     TaskGraph g;
     std::vector<std::vector<ComputeNode*>> levels;
-    std::map<int, std::unique_ptr<Context>> contexts;
+    std::vector<std::vector<ComputeNode*>> shared_levels;                  // key export/load: before every chunk
+    std::vector<std::vector<std::vector<ComputeNode*>>> chunk_levels;      // [chunk][level] -> nodes; empty: not pipelined
+    std::map<int, std::unique_ptr<Context>> contexts;                      // key = 2*device + lane
     std::map<int, hipStream_t> streams;
-    Pinned stage;
-    std::vector<std::shared_ptr<Slab>> pending_free;   // temporaries still referenced by enqueued work
+    std::vector<std::shared_ptr<Slab>> pending_free_[2];   // temporaries still referenced by enqueued work, per lane
+    std::vector<std::shared_ptr<Slab>>& pending_free_ref() { return pending_free_[cur_lane]; }
+#define pending_free pending_free_ref()
     int last_gpu_nodes = 0, last_gpu_batches = 0;
     double last_ms = 0;
 
@@ -285,16 +296,103 @@ struct fhe_task_handle_st {
         for (auto& kv : g.computes) levels[kv.second.sched_meta.top_level].push_back(&kv.second);
         for (auto& lv : levels)
             std::sort(lv.begin(), lv.end(), [](const ComputeNode* a, const ComputeNode* b) { return a->index < b->index; });
+        if (!getenv("LSA_NO_PIPELINE")) plan_pipeline();
+    }
+
+    // Independent subgraphs = connected components of the compute nodes over the non-key data (evaluation keys are shared
+    // read-only inputs).  Pipelining needs the simple shape every benchmark graph has: per chunk, CPU nodes only before
+    // the loads and after the stores, and all stores in one level.
+    void plan_pipeline() {
+        auto is_key = [](const DatumNode* d) {
+            return d->datum_type == TYPE_RELIN_KEY || d->datum_type == TYPE_GALOIS_KEY || d->datum_type == TYPE_SWITCH_KEY;
+        };
+        std::unordered_map<const ComputeNode*, const ComputeNode*> parent;
+        std::function<const ComputeNode*(const ComputeNode*)> find = [&](const ComputeNode* x) {
+            while (parent[x] != x) x = parent[x] = parent[parent[x]];
+            return x;
+        };
+        for (auto& kv : g.computes) parent[&kv.second] = &kv.second;
+        std::unordered_set<const ComputeNode*> key_only;
+        for (auto& kv : g.computes) {
+            bool all_key = true;
+            for (auto* d : kv.second.input_nodes) all_key = all_key && is_key(d);
+            for (auto* d : kv.second.output_nodes) all_key = all_key && is_key(d);
+            if (all_key) key_only.insert(&kv.second);
+        }
+        for (auto& kv : g.data) {
+            const DatumNode& d = kv.second;
+            if (is_key(&d)) continue;
+            const ComputeNode* first = nullptr;
+            auto join = [&](const ComputeNode* c) {
+                if (!first) first = c;
+                else parent[find(c)] = find(first);
+            };
+            for (auto* c : d.predecessors) join(c);
+            for (auto* c : d.successors) join(c);
+        }
+        std::map<NodeIndex, const ComputeNode*> comps;   // smallest node index -> representative
+        std::unordered_map<const ComputeNode*, NodeIndex> lowest;
+        for (auto& kv : g.computes) {
+            if (key_only.count(&kv.second)) continue;
+            const ComputeNode* r = find(&kv.second);
+            auto it = lowest.find(r);
+            if (it == lowest.end() || kv.first < it->second) lowest[r] = kv.first;
+        }
+        for (auto& kv : lowest) comps[kv.second] = kv.first;
+        if (comps.size() < 4) return;
+        // worth it only when the copies dominate: small graphs keep the whole-level batches (fewer, larger launches)
+        double in_bytes = 0;
+        const double n_ring = (double)g.parameter["n"].as_int();
+        for (NodeIndex idx : g.inputs) {
+            const DatumNode& d = g.data.at(idx);
+            if (is_key(&d) || !d.fhe_prop) continue;
+            const bool ringt = d.fhe_prop->p && d.fhe_prop->p->is_ringt;
+            in_bytes += 8.0 * n_ring * (d.datum_type == TYPE_CIPHERTEXT ? d.fhe_prop->degree + 1 : 1) * (ringt ? 1 : d.fhe_prop->level + 1);
+        }
+        const char* min_mib = getenv("LSA_PIPELINE_MIN_MIB");   // tests force the pipelined path on small graphs with 0
+        if (in_bytes < (min_mib ? atof(min_mib) : 256.0) * 1048576.0) return;
+        const int nchunks = (int)std::min<size_t>(8, comps.size() / 2);
+        std::unordered_map<const ComputeNode*, int> chunk_of;
+        int ci = 0;
+        for (auto& kv : comps) chunk_of[kv.second] = (int)((long long)ci++ * nchunks / (long long)comps.size());
+        std::vector<std::vector<std::vector<ComputeNode*>>> cl(nchunks, std::vector<std::vector<ComputeNode*>>(levels.size()));
+        std::vector<std::vector<ComputeNode*>> sh(levels.size());
+        for (size_t l = 0; l < levels.size(); l++)
+            for (ComputeNode* n : levels[l]) {
+                if (key_only.count(n)) sh[l].push_back(n);
+                else cl[chunk_of.at(find(n))][l].push_back(n);
+            }
+        for (auto& chunk : cl) {   // shape check
+            int first_load = -1, store_level = -1;
+            for (size_t l = 0; l < chunk.size(); l++)
+                for (ComputeNode* n : chunk[l]) {
+                    if (n->op() == OperationType::LOAD_TO_BACKEND && first_load < 0) first_load = (int)l;
+                    if (n->op() == OperationType::STORE_FROM_BACKEND) {
+                        if (store_level >= 0 && store_level != (int)l) return;
+                        store_level = (int)l;
+                    }
+                }
+            if (first_load < 0 || store_level < 0) return;
+            for (size_t l = 0; l < chunk.size(); l++)
+                for (ComputeNode* n : chunk[l]) {
+                    if (n->on_cpu && (int)l >= first_load && (int)l <= store_level) return;
+                    // from the store level on: nothing but the stores themselves and CPU-side nodes
+                    if ((int)l >= store_level && !n->on_cpu && n->op() != OperationType::STORE_FROM_BACKEND) return;
+                }
+        }
+        shared_levels = std::move(sh);
+        chunk_levels = std::move(cl);
     }
     ~fhe_task_handle_st() {
         for (auto& kv : streams) {
-            (void)hipSetDevice(kv.first);
+            (void)hipSetDevice(kv.first / 2);
             (void)hipStreamDestroy(kv.second);
         }
     }
 
-    Context& context(int device) {
-        auto it = contexts.find(device);
+    Context& context(int device, int lane = 0) {
+        const int key = 2 * device + lane;
+        auto it = contexts.find(key);
         if (it != contexts.end()) {
             it->second->use_device();
             return *it->second;
@@ -311,15 +409,16 @@ struct fhe_task_handle_st {
                                            p.data(), (int)p.size(), t, device);
         hipStream_t s;
         LSA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        streams[device] = s;
+        streams[key] = s;
         Context& ref = *c;
-        contexts[device] = std::move(c);
+        contexts[key] = std::move(c);
         return ref;
     }
 
     // ---------------------------------------------------------------- LOAD_TO_BACKEND (batched H2D)
-    void run_loads(Context& c, hipStream_t s, const std::vector<ComputeNode*>& nodes,
-                   std::unordered_map<NodeIndex, std::any>& avail) {
+    // returns the pinned staging slab: it must outlive the enqueued copies (the caller synchronises or keeps it)
+    std::shared_ptr<Slab> run_loads(Context& c, hipStream_t s, const std::vector<ComputeNode*>& nodes,
+                                    std::unordered_map<NodeIndex, std::any>& avail) {
         const long long N = c.n;
         // 1. ciphertexts / plaintexts grouped into one slab per (kind, polys, level) in node order
         struct Item {
@@ -391,9 +490,10 @@ struct fhe_task_handle_st {
             total += (size_t)k.beta * 2 * k.comp * N;
             keys.push_back(std::move(k));
         }
-        if (total == 0) return;
-        // 2. gather limbs into the pinned staging slab, one H2D copy per group
-        u64* host = stage.ensure(total);
+        if (total == 0) return nullptr;
+        // 2. gather limbs into a pinned staging slab, one H2D copy per group
+        auto hstage = std::make_shared<Slab>(pin_pool, total);
+        u64* host = hstage->ptr;
         struct Job {
             u64* dst;
             const u64* src;
@@ -473,12 +573,23 @@ struct fhe_task_handle_st {
             launch_to_mont(c, dk->key.data, k.beta * 2 * k.comp, rm, s);
             avail[k.node->output_nodes[0]->index] = dk;
         }
-        LSA_HIP(hipStreamSynchronize(s));  // staging slab is reused by the next level
+        return hstage;
     }
 
     // ---------------------------------------------------------------- STORE_FROM_BACKEND (batched D2H)
+    struct StoreJob {
+        std::vector<ComputeNode*> nodes;
+        std::vector<std::pair<DatumP, size_t>> items;
+        std::shared_ptr<Slab> hslab;
+    };
     void run_stores(Context& c, hipStream_t s, const std::vector<ComputeNode*>& nodes,
                     std::unordered_map<NodeIndex, std::any>& avail) {
+        StoreJob j = stores_enqueue(c, s, nodes, avail);
+        LSA_HIP(hipStreamSynchronize(s));
+        stores_finish(c, j, avail);
+    }
+    StoreJob stores_enqueue(Context& c, hipStream_t s, const std::vector<ComputeNode*>& nodes,
+                            std::unordered_map<NodeIndex, std::any>& avail) {
         const long long N = c.n;
         size_t total = 0;
         std::vector<std::pair<DatumP, size_t>> items;
@@ -503,7 +614,15 @@ struct fhe_task_handle_st {
             LSA_HIP(hipMemcpyAsync(host + items[i].second, items[i].first->ptr, words * sizeof(u64), hipMemcpyDeviceToHost, s));
             i = j;
         }
-        LSA_HIP(hipStreamSynchronize(s));
+        return StoreJob{nodes, std::move(items), hslab};
+    }
+    // after the stream has been synchronised: wrap the pinned result slab into C structs for the import executor
+    void stores_finish(Context& c, StoreJob& job, std::unordered_map<NodeIndex, std::any>& avail) {
+        const long long N = c.n;
+        const auto& nodes = job.nodes;
+        const auto& items = job.items;
+        auto hslab = job.hslab;
+        u64* host = hslab->ptr;
         for (size_t i = 0; i < nodes.size(); i++) {
             const DatumP& d = items[i].first;
             auto* ct = (CCiphertext*)malloc(sizeof(CCiphertext));
@@ -813,7 +932,7 @@ struct fhe_task_handle_st {
              int device) {
         const auto t_start = std::chrono::steady_clock::now();
         Context& c = context(device);
-        hipStream_t s = streams.at(device);
+        hipStream_t s = streams.at(2 * device);
         // inputs: flatten every CArgument's handle array, consume in mega_ag.inputs order; all Galois-key data nodes share
         // the first Galois handle (cpu_task_utils.h:235-319)
         std::vector<void*> handles;
@@ -856,58 +975,156 @@ struct fhe_task_handle_st {
         auto last_cb = std::chrono::steady_clock::now() - std::chrono::seconds(1);
         last_gpu_nodes = last_gpu_batches = 0;
 
-        for (auto& level : levels) {
-            std::vector<ComputeNode*> cpu, loads, stores;
-            std::map<std::string, std::vector<ComputeNode*>> buckets;
-            std::vector<std::string> bucket_order;
-            for (ComputeNode* n : level) {
-                if (n->on_cpu) cpu.push_back(n);
-                else if (n->op() == OperationType::LOAD_TO_BACKEND) loads.push_back(n);
-                else if (n->op() == OperationType::STORE_FROM_BACKEND) stores.push_back(n);
-                else {
-                    const std::string sg = signature(n);
-                    if (!buckets.count(sg)) bucket_order.push_back(sg);
-                    buckets[sg].push_back(n);
-                }
-            }
-            const bool trace = getenv("LSA_TASK_TRACE") != nullptr;
-            auto tick = [&]() { return std::chrono::steady_clock::now(); };
-            auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
-                return std::chrono::duration<double, std::milli>(tick() - t0).count();
-            };
-            auto t0 = tick();
-            if (!loads.empty()) run_loads(c, s, loads, avail);
-            const double t_load = ms_since(t0);
-            t0 = tick();
-            for (auto& sg : bucket_order) {
-                run_gpu_bucket(c, s, buckets[sg], avail);
-                last_gpu_nodes += (int)buckets[sg].size();
-                last_gpu_batches++;
-            }
-            if (trace && !bucket_order.empty()) LSA_HIP(hipStreamSynchronize(s));
-            const double t_gpu = ms_since(t0);
-            t0 = tick();
-            if (!stores.empty()) run_stores(c, s, stores, avail);
-            const double t_store = ms_since(t0);
-            t0 = tick();
-            run_cpu_nodes(cpu, avail, out_handles);
-            const double t_cpu = ms_since(t0);
-            if (trace)
-                fprintf(stderr, "[lsa task] level: %zu nodes  load %.2f ms  gpu %.2f ms  store %.2f ms  cpu %.2f ms\n",
-                        level.size(), t_load, t_gpu, t_store, t_cpu);
-            for (ComputeNode* n : level)
-                for (auto* in : n->input_nodes)
-                    if (--refs[in->index] <= 0 && !in->is_input && !in->is_output) avail.erase(in->index);
-            if (!pending_free.empty()) {  // slabs whose last reference is dropped here are freed after their readers ran
-                LSA_HIP(hipStreamSynchronize(s));
-                pending_free.clear();
-            }
-            completed += (int)level.size();
+        const bool trace = getenv("LSA_TASK_TRACE") != nullptr;
+        auto tick = [&]() { return std::chrono::steady_clock::now(); };
+        auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+            return std::chrono::duration<double, std::milli>(tick() - t0).count();
+        };
+        auto progress = [&](size_t nodes_done) {
+            completed += (int)nodes_done;
             const auto now = std::chrono::steady_clock::now();
             if (cb && (completed == total || now - last_cb >= std::chrono::milliseconds(100))) {
                 cb(completed, total, user);
                 last_cb = now;
             }
+        };
+        auto release_inputs = [&](const std::vector<ComputeNode*>& level) {
+            for (ComputeNode* n : level)
+                for (auto* in : n->input_nodes)
+                    if (--refs[in->index] <= 0 && !in->is_input && !in->is_output) avail.erase(in->index);
+        };
+        struct Split {
+            std::vector<ComputeNode*> cpu, loads, stores;
+            std::map<std::string, std::vector<ComputeNode*>> buckets;
+            std::vector<std::string> bucket_order;
+        };
+        auto split = [&](const std::vector<ComputeNode*>& level) {
+            Split sp;
+            for (ComputeNode* n : level) {
+                if (n->on_cpu) sp.cpu.push_back(n);
+                else if (n->op() == OperationType::LOAD_TO_BACKEND) sp.loads.push_back(n);
+                else if (n->op() == OperationType::STORE_FROM_BACKEND) sp.stores.push_back(n);
+                else {
+                    const std::string sg = signature(n);
+                    if (!sp.buckets.count(sg)) sp.bucket_order.push_back(sg);
+                    sp.buckets[sg].push_back(n);
+                }
+            }
+            return sp;
+        };
+        // one level, everything in order on one lane, host-synchronous at the copies (graphs that are not pipelined)
+        auto run_level_sync = [&](const std::vector<ComputeNode*>& level) {
+            if (level.empty()) return;
+            Split sp = split(level);
+            auto t0 = tick();
+            if (!sp.loads.empty()) {
+                auto keep = run_loads(c, s, sp.loads, avail);
+                LSA_HIP(hipStreamSynchronize(s));
+            }
+            const double t_load = ms_since(t0);
+            t0 = tick();
+            for (auto& sg : sp.bucket_order) {
+                run_gpu_bucket(c, s, sp.buckets[sg], avail);
+                last_gpu_nodes += (int)sp.buckets[sg].size();
+                last_gpu_batches++;
+            }
+            if (trace && !sp.bucket_order.empty()) LSA_HIP(hipStreamSynchronize(s));
+            const double t_gpu = ms_since(t0);
+            t0 = tick();
+            if (!sp.stores.empty()) run_stores(c, s, sp.stores, avail);
+            const double t_store = ms_since(t0);
+            t0 = tick();
+            run_cpu_nodes(sp.cpu, avail, out_handles);
+            const double t_cpu = ms_since(t0);
+            if (trace)
+                fprintf(stderr, "[lsa task] level: %zu nodes  load %.2f ms  gpu %.2f ms  store %.2f ms  cpu %.2f ms\n",
+                        level.size(), t_load, t_gpu, t_store, t_cpu);
+            release_inputs(level);
+            if (!pending_free.empty()) {  // slabs whose last reference is dropped here are freed after their readers ran
+                LSA_HIP(hipStreamSynchronize(s));
+                pending_free.clear();
+            }
+            progress(level.size());
+        };
+
+        if (chunk_levels.empty()) {
+            for (auto& level : levels) run_level_sync(level);
+        } else {
+            // shared evaluation keys first (lane 0); lane 1 waits for them on the device
+            for (auto& level : shared_levels) run_level_sync(level);
+            Context& c1 = context(device, 1);
+            hipStream_t s1 = streams.at(2 * device + 1);
+            LSA_HIP(hipStreamSynchronize(s));
+            struct InFlight {
+                int chunk = -1, lane = 0;
+                size_t resume_level = 0;
+                StoreJob job;
+                std::vector<std::shared_ptr<Slab>> keep;
+            };
+            auto finish = [&](InFlight& f) {
+                if (f.chunk < 0) return;
+                cur_lane = f.lane;
+                Context& lc = f.lane ? c1 : c;
+                hipStream_t ls = f.lane ? s1 : s;
+                auto t0 = tick();
+                LSA_HIP(hipStreamSynchronize(ls));
+                const double t_wait = ms_since(t0);
+                pending_free.clear();
+                f.keep.clear();
+                auto& cl = chunk_levels[f.chunk];
+                t0 = tick();
+                stores_finish(lc, f.job, avail);
+                {   // the store level's bookkeeping, then the CPU-side tail (import executors)
+                    release_inputs(cl[f.resume_level]);
+                    progress(cl[f.resume_level].size());
+                }
+                for (size_t l = f.resume_level + 1; l < cl.size(); l++) {
+                    if (cl[l].empty()) continue;
+                    Split sp = split(cl[l]);
+                    LSA_REQUIRE(sp.loads.empty() && sp.stores.empty() && sp.bucket_order.empty(), "pipeline plan violated");
+                    run_cpu_nodes(sp.cpu, avail, out_handles);
+                    release_inputs(cl[l]);
+                    progress(cl[l].size());
+                }
+                if (trace) fprintf(stderr, "[lsa task] chunk %d lane %d: waited %.2f ms, import %.2f ms\n", f.chunk, f.lane, t_wait, ms_since(t0));
+                f.chunk = -1;
+            };
+            InFlight fly[2];
+            for (size_t ch = 0; ch < chunk_levels.size(); ch++) {
+                const int lane = (int)(ch & 1);
+                finish(fly[lane]);            // the lane's previous chunk (two chunks in flight at most)
+                cur_lane = lane;
+                Context& lc = lane ? c1 : c;
+                hipStream_t ls = lane ? s1 : s;
+                lc.use_device();
+                InFlight& f = fly[lane];
+                f.chunk = (int)ch;
+                f.lane = lane;
+                auto& cl = chunk_levels[ch];
+                auto t0 = tick();
+                for (size_t l = 0; l < cl.size(); l++) {
+                    if (cl[l].empty()) continue;
+                    Split sp = split(cl[l]);
+                    if (!sp.stores.empty()) {     // copy-out enqueued; the rest of the chunk happens in finish()
+                        f.job = stores_enqueue(lc, ls, sp.stores, avail);
+                        f.resume_level = l;
+                        break;
+                    }
+                    if (!sp.cpu.empty()) run_cpu_nodes(sp.cpu, avail, out_handles);   // export executors
+                    if (!sp.loads.empty()) f.keep.push_back(run_loads(lc, ls, sp.loads, avail));
+                    for (auto& sg : sp.bucket_order) {
+                        run_gpu_bucket(lc, ls, sp.buckets[sg], avail);
+                        last_gpu_nodes += (int)sp.buckets[sg].size();
+                        last_gpu_batches++;
+                    }
+                    release_inputs(cl[l]);
+                    progress(cl[l].size());
+                }
+                if (trace) fprintf(stderr, "[lsa task] chunk %zu lane %d: enqueued in %.2f ms\n", ch, lane, ms_since(t0));
+            }
+            finish(fly[0]);
+            finish(fly[1]);
+            cur_lane = 0;
         }
         LSA_HIP(hipStreamSynchronize(s));
         last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();

@@ -369,3 +369,63 @@ def test_ckks_conv2d_application_graph():
     re, im = mean_precision_bits(msg, c.ckks_decrypt(out[0].data, s))
     assert re >= 10 and im >= 10
     t.close()
+
+
+def test_pipelined_lanes_match_the_sequential_run(monkeypatch):
+    """Graphs made of independent subgraphs are pipelined over two lanes (stream + context + buffer pool each) when the
+    copies dominate; forced here on small fixtures: same bits as the oracle, shared keys loaded once, one launch group per
+    chunk and operator."""
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, GaloisKey, KeySwitchKey
+    from oracle.client import galois_element_for_col_rotation
+    monkeypatch.setenv("LSA_PIPELINE_MIN_MIB", "0")
+    g, P, o, c = _load("ckks_n4096_cmc_relin_rescale")
+    n, lvl = P["n"], 4
+    _, xs = _ckks_inputs(c, n, lvl, N_OP, 31)
+    _, ys = _ckks_inputs(c, n, lvl, N_OP, 32)
+    rlk = c.gen_relin_key(lvl)
+    t = _task("ckks_n4096_cmc_relin_rescale")
+    zs = [Ciphertext.empty(1, lvl - 1, n) for _ in range(N_OP)]
+    seen = []
+    for _ in range(2):      # second run: pooled buffers of both lanes are reused
+        t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
+               Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("out_z_list", zs)],
+              progress_cb=lambda d, tot: seen.append((d, tot)))
+        st = t.last_run_stats()
+        assert st["gpu_nodes"] == N_OP and st["gpu_batches"] == 2       # 2 chunks x 1 fused operator
+        assert seen[-1][0] == seen[-1][1]
+        for i in range(N_OP):
+            assert np.array_equal(zs[i].data, o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk, lvl))
+    t.close()
+    # rotations: the Galois keys are shared by every chunk
+    g, P, o, c = _load("ckks_n4096_advanced_rotate_col")
+    lvl, steps = 3, [1, 2, 5]
+    _, xs = _ckks_inputs(c, n, lvl, N_OP, 33)
+    elts = {s: galois_element_for_col_rotation(s, n) for s in steps}
+    keys = {e: c.gen_galois_key(e, lvl) for e in elts.values()}
+    glk = GaloisKey({e: KeySwitchKey(k, lvl, len(P["p"])) for e, k in keys.items()})
+    t = _task("ckks_n4096_advanced_rotate_col")
+    ys = [Ciphertext.empty(1, lvl, n) for _ in range(N_OP * len(steps))]
+    t.run([Argument("arg_x", [Ciphertext(x) for x in xs]), Argument("glk_ntt", [glk])], [Argument("arg_y", ys)])
+    assert t.last_run_stats()["gpu_batches"] == 2 * len(steps)
+    for i in range(N_OP):
+        for j, s in enumerate(steps):
+            assert np.array_equal(ys[i * len(steps) + j].data, o.ckks_rotate(lvl, xs[i], elts[s], keys[elts[s]], lvl))
+    t.close()
+    # BFV mult+relin
+    from lattisense_amd.task import Ciphertext as Ct
+    g, P, o, c = _load("bfv_n4096_cmc_relin")
+    lvl = 3
+    rng = np.random.default_rng(34)
+    xm = [rng.integers(0, P["t"], n) for _ in range(N_OP)]
+    ym = [rng.integers(0, P["t"], n) for _ in range(N_OP)]
+    xs = [c.bfv_encrypt(m, lvl) for m in xm]
+    ys = [c.bfv_encrypt(m, lvl) for m in ym]
+    rlk = c.gen_relin_key(lvl)
+    t = _task("bfv_n4096_cmc_relin")
+    zs = [Ct.empty(1, lvl, n) for _ in range(N_OP)]
+    t.run([Argument("xs", [Ct(x) for x in xs]), Argument("ys", [Ct(y) for y in ys]),
+           Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("zs", zs)])
+    for i in range(N_OP):
+        assert np.array_equal(zs[i].data, o.bfv_mult_relin(lvl, xs[i], ys[i], rlk, lvl))
+    t.close()
