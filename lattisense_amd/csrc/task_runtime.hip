@@ -76,8 +76,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ device data
 // Buffers (device or pinned host) recycled across levels and run() calls: hipMalloc/hipFree and pinned allocation cost
-// milliseconds and synchronise the device, so a task keeps what it allocated.  All work of a run is on one in-order
-// stream, so handing a released device buffer to a later kernel is ordered after its earlier readers.
+// milliseconds and synchronise the device, so a task keeps what it allocated.  Every device pool belongs to ONE lane (one
+// in-order stream), so handing a released device buffer to a later kernel is ordered after its earlier readers.
 struct BufPool {
     bool pinned;
     std::mutex mu;
@@ -174,24 +174,6 @@ struct DevKey {
 using DatumP = std::shared_ptr<DevDatum>;
 using KeyP = std::shared_ptr<DevKey>;
 
-struct Pinned {
-    u64* ptr = nullptr;
-    size_t words = 0;
-    u64* ensure(size_t w) {
-        if (w > words) {
-            if (ptr) (void)hipHostFree(ptr);
-            ptr = nullptr;
-            words = 0;
-            LSA_HIP(hipHostMalloc((void**)&ptr, w * sizeof(u64), hipHostMallocDefault));
-            words = w;
-        }
-        return ptr;
-    }
-    ~Pinned() {
-        if (ptr) (void)hipHostFree(ptr);
-    }
-};
-
 const char* op_name(OperationType op) {
     switch (op) {
         case OperationType::ADD: return "add";
@@ -278,8 +260,7 @@ struct fhe_task_handle_st {
     std::map<int, std::unique_ptr<Context>> contexts;                      // key = 2*device + lane
     std::map<int, hipStream_t> streams;
     std::vector<std::shared_ptr<Slab>> pending_free_[2];   // temporaries still referenced by enqueued work, per lane
-    std::vector<std::shared_ptr<Slab>>& pending_free_ref() { return pending_free_[cur_lane]; }
-#define pending_free pending_free_ref()
+    std::vector<std::shared_ptr<Slab>>& pending_free() { return pending_free_[cur_lane]; }
     int last_gpu_nodes = 0, last_gpu_batches = 0;
     double last_ms = 0;
 
@@ -673,7 +654,7 @@ struct fhe_task_handle_st {
             LSA_HIP(hipMemcpyAsync(o.keep->ptr + words * i, d[i]->ptr, words * sizeof(u64), hipMemcpyDeviceToDevice, s));
         o.ptr = o.keep->ptr;
         o.stride = (long long)words;
-        pending_free.push_back(o.keep);
+        pending_free().push_back(o.keep);
         return o;
     }
 
@@ -721,7 +702,7 @@ struct fhe_task_handle_st {
             if (!is_ringt_node(n0->input_nodes[pos])) return gather(c, s, nodes, pos, avail, (size_t)L * N);
             Operand raw = gather(c, s, nodes, pos, avail, (size_t)N);
             Operand o{nullptr, (long long)L * N, dslab((size_t)m * L * N)};
-            pending_free.push_back(o.keep);
+            pending_free().push_back(o.keep);
             launch_lift_ringt(c, ringt_mode, lvl, raw.ptr, raw.stride, o.keep->ptr, o.stride, m, s);
             if (to_ntt) launch_ntt(c, o.keep->ptr, o.keep->ptr, m, o.stride, L, rmL, false, s);
             o.ptr = o.keep->ptr;
@@ -729,7 +710,7 @@ struct fhe_task_handle_st {
         };
         auto temp = [&](size_t words) {
             auto sl = dslab(words);
-            pending_free.push_back(sl);
+            pending_free().push_back(sl);
             return sl->ptr;
         };
 
@@ -883,7 +864,7 @@ struct fhe_task_handle_st {
             d->level = out_lvl;
             avail[nodes[i]->output_nodes[0]->index] = d;
         }
-        pending_free.push_back(out_slab);  // (cheap: shared) keeps frees off the critical path until the level ends
+        pending_free().push_back(out_slab);  // (cheap: shared) keeps frees off the critical path until the level ends
     }
 
     // ---------------------------------------------------------------- CPU-side nodes (export / import / custom)
@@ -1040,9 +1021,9 @@ struct fhe_task_handle_st {
                 fprintf(stderr, "[lsa task] level: %zu nodes  load %.2f ms  gpu %.2f ms  store %.2f ms  cpu %.2f ms\n",
                         level.size(), t_load, t_gpu, t_store, t_cpu);
             release_inputs(level);
-            if (!pending_free.empty()) {  // slabs whose last reference is dropped here are freed after their readers ran
+            if (!pending_free().empty()) {  // slabs whose last reference is dropped here are freed after their readers ran
                 LSA_HIP(hipStreamSynchronize(s));
-                pending_free.clear();
+                pending_free().clear();
             }
             progress(level.size());
         };
@@ -1069,7 +1050,7 @@ struct fhe_task_handle_st {
                 auto t0 = tick();
                 LSA_HIP(hipStreamSynchronize(ls));
                 const double t_wait = ms_since(t0);
-                pending_free.clear();
+                pending_free().clear();
                 f.keep.clear();
                 auto& cl = chunk_levels[f.chunk];
                 t0 = tick();
