@@ -129,6 +129,29 @@ int lsa_set_fuse_tails(lsa_context ctx, int enable);
 /* Two-pass NTTs (N > 2^12) run both passes over a chunk of at most `mib` MiB of limbs before moving on, so that the
  * second pass is served by the 256 MiB Infinity Cache (0 = one launch per pass over the whole batch). */
 int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib);
+/* ---- CKKS bootstrapping: the `bootstrap` node of a task graph (reference: mega_ag_executors_gpu.cu:410-426 calls HEonGPU's
+ * regular_bootstrapping_v2; configuration gpu_wrapper.cu:86-117 / custom_task.py:383-468).  A plan holds the encoded
+ * CoeffsToSlots / SlotsToCoeffs diagonals (depths cts_depth / stc_depth, full-slot encoding), the EvalMod constants
+ * (cosine of range k with `double_angle` doublings, message ratio) and the list of Galois elements a run needs -- the
+ * rotation set of the reference's planner (frontend/bootstrap_params.py:104-263) plus the conjugation.  in_scale: scale
+ * of the level-0 input; out_scale: scale the refreshed ciphertext must have (0: whatever falls out).  The context's chain
+ * must have cts_depth + 5 + double_angle + stc_depth levels above the output level.
+ * lsa_ckks_bootstrap: in [batch][2][1][N] -> out [batch][2][out_level+1][N]; swk_dts / swk_std (both or neither) are the
+ * sparse-secret encapsulation keys at level 0 / top level (custom_task.py:1989-1996). */
+typedef struct lsa_bootstrap_st* lsa_bootstrap;
+int lsa_bootstrap_create(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
+                         double in_scale, double out_scale, void* stream, lsa_bootstrap* out);
+void lsa_bootstrap_destroy(lsa_bootstrap b);
+int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* n_galois, int* n_matrices, int* n_cts);
+int lsa_bootstrap_galois_elements(lsa_bootstrap b, uint64_t* out, int capacity);
+/* the plan's floating-point constants, exported so that a checker can replay the program with the same integers */
+int lsa_bootstrap_chebyshev(lsa_bootstrap b, double* out32);
+int lsa_bootstrap_matrix_info(lsa_bootstrap b, int index, int* level, int* n1, int* n_diagonals, int* diagonals, int capacity);
+int lsa_bootstrap_plaintext(lsa_bootstrap b, int matrix, int diag_pos, uint64_t* host_out);
+int lsa_ckks_bootstrap(lsa_context ctx, lsa_bootstrap b, const uint64_t* in, uint64_t* out, int batch, long long sin, long long sout,
+                       lsa_key rlk, int n_glk, const uint64_t* glk_elements, const lsa_key* glk, lsa_key swk_dts, lsa_key swk_std,
+                       void* stream);
+
 /* diagnostic builds only (-DLSA_NTT_DIAG_STAMPS): device buffer of 8192*8 u64 receiving per-workgroup phase time stamps
  * of every following NTT launch; NULL turns it off.  Ignored by the normal build. */
 int lsa_debug_set_ntt_stamps(lsa_context ctx, void* device_buffer);

@@ -77,6 +77,18 @@ SIGNATURES = {
     "lsa_set_fuse_tails": (c_int, [c_vp, c_int]),
     "lsa_set_ntt_chunk_mib": (c_int, [c_vp, c_int]),
     "lsa_debug_set_ntt_stamps": (c_int, [c_vp, c_vp]),
+    "lsa_bootstrap_create": (c_int, [c_vp, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp,
+                                     ctypes.POINTER(c_vp)]),
+    "lsa_bootstrap_destroy": (None, [c_vp]),
+    "lsa_bootstrap_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
+                                   ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "lsa_bootstrap_galois_elements": (c_int, [c_vp, c_u64p, c_int]),
+    "lsa_bootstrap_chebyshev": (c_int, [c_vp, ctypes.POINTER(ctypes.c_double)]),
+    "lsa_bootstrap_matrix_info": (c_int, [c_vp, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                          ctypes.POINTER(c_int), c_int]),
+    "lsa_bootstrap_plaintext": (c_int, [c_vp, c_int, c_int, c_u64p]),
+    "lsa_ckks_bootstrap": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, ctypes.c_longlong, ctypes.c_longlong, c_vp, c_int, c_u64p,
+                                   ctypes.POINTER(c_vp), c_vp, c_vp, c_vp]),
     "lsa_profile_begin": (c_int, [c_vp, c_int]),
     "lsa_profile_end": (c_int, [c_vp]),
     "lsa_profile_read": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblattisense_amd.so")
-HIP_SOURCES = ["kernels.hip", "context.hip", "ops.hip", "c_api.hip", "task_runtime.hip"]
+HIP_SOURCES = ["kernels.hip", "context.hip", "ops.hip", "bootstrap.hip", "c_api.hip", "task_runtime.hip"]
 CXX_SOURCES = ["tables.cpp", "task_graph.cpp"]
 HEADERS = ["modarith.h", "ntt_core.h", "ntt_plan.h", "tables.h", "lsa_internal.h", "task_graph.h", "mini_json.h",
            "../../include/lattisense_amd.h", "../../include/lattisense_task.h"]

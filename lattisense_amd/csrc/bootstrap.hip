@@ -1,0 +1,699 @@
+// bootstrap.hip — CKKS bootstrapping as a program of the device operators (the `bootstrap` node of a task graph).
+//
+// Reference: mega_ag_runners/gpu/mega_ag_executors_gpu.cu:410-426 hands the ciphertext to HEonGPU's
+// regular_bootstrapping_v2 (absent submodule); parameters mega_ag_runners/gpu/gpu_wrapper.cu:86-117 and
+// frontend/custom_task.py:383-468; the rotations a caller generates Galois keys for: frontend/bootstrap_params.py:104-263.
+// The algorithm is the one restated (and explained) in oracle/ckks_bootstrap.py, which is also its oracle:
+//   scale-up by an integer -> (switch to the sparse secret) -> ModRaise -> (switch back) -> CoeffsToSlots (merged radix-2
+//   layers of the inverse special FFT, baby-step / giant-step with the planner's split) -> conjugate split into real and
+//   imaginary coefficients -> EvalMod (Chebyshev interpolant of cos on [-1,1] by binary splitting, double-angle steps) ->
+//   recombine -> SlotsToCoeffs.
+// Only floating-point CONSTANTS are computed here (the encoded diagonals, the Chebyshev coefficients); every operation on
+// ciphertexts is one of the integer operators of ops.hip / kernels.hip, so a replay of the same program with the same
+// constants on the CPU oracle gives identical residues (tests/test_gpu_bootstrap.py).
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdlib>
+#include <functional>
+#include <map>
+#include <memory>
+
+#include "lsa_internal.h"
+
+namespace lsa {
+
+void ckks_rescale(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
+void ckks_rotate(Context&, int, const u64*, u64, const Key&, u64*, int, long long, long long, hipStream_t);
+void ckks_switch_key(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
+void ckks_mult_relin_rescale(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long, long long,
+                             hipStream_t);
+
+using cplx = std::complex<double>;
+using Diags = std::map<int, std::vector<cplx>>;   // diagonal k: d[t] multiplies x[(t + k) mod n]
+
+namespace {
+
+const double kPi = 3.14159265358979323846;
+
+std::vector<int> rot_group(int n_slots) {
+    std::vector<int> g(n_slots);
+    long long v = 1;
+    const long long m = 4LL * n_slots;
+    for (int i = 0; i < n_slots; i++) {
+        g[i] = (int)v;
+        v = v * 5 % m;
+    }
+    return g;
+}
+
+// one radix-2 layer of the special FFT (forward: slots <- coefficients) or of its inverse, as three diagonals
+Diags layer_diagonals(int n, int length, bool inverse, const std::vector<int>& rg) {
+    const long long m = 4LL * n;
+    const int lenh = length / 2;
+    const long long lenq = 4LL * length;
+    std::vector<cplx> d0(n), dp(n), dm(n);
+    auto root = [&](long long idx) { return std::polar(1.0, 2.0 * kPi * (double)idx / (double)m); };
+    for (int t = 0; t < n; t++) {
+        const int j = t % length;
+        if (j < lenh) {
+            d0[t] = 1.0;
+            dp[t] = inverse ? cplx(1.0) : root((rg[j] % lenq) * (m / lenq));
+        } else {
+            const int jj = j - lenh;
+            if (inverse) {
+                const cplx w = root((lenq - (rg[jj] % lenq)) * (m / lenq));
+                d0[t] = -w;
+                dm[t] = w;
+            } else {
+                d0[t] = -root((rg[jj] % lenq) * (m / lenq));
+                dm[t] = 1.0;
+            }
+        }
+    }
+    Diags out;
+    out[0] = d0;
+    const int kp = lenh % n, km = ((-lenh) % n + n) % n;
+    if (kp == km) {   // the widest layer: +n/2 and -n/2 are the same rotation
+        for (int t = 0; t < n; t++) dp[t] += dm[t];
+        out[kp] = dp;
+    } else {
+        out[kp] = dp;
+        out[km] = dm;
+    }
+    return out;
+}
+
+// diagonals of (second o first)
+Diags compose(const Diags& first, const Diags& second, int n) {
+    Diags out;
+    for (auto& a : second)
+        for (auto& b : first) {
+            const int k = (a.first + b.first) % n;
+            auto& dst = out[k];
+            if (dst.empty()) dst.assign(n, cplx(0.0));
+            for (int t = 0; t < n; t++) dst[t] += a.second[t] * b.second[(t + a.first) % n];
+        }
+    for (auto it = out.begin(); it != out.end();) {
+        double mx = 0;
+        for (auto& v : it->second) mx = std::max(mx, std::abs(v));
+        it = mx > 1e-300 ? std::next(it) : out.erase(it);
+    }
+    return out;
+}
+
+// `depth` merged groups in application order, grouped like frontend/bootstrap_params.py:104-119
+std::vector<Diags> merged_matrices(int n, int depth, bool inverse) {
+    int log_n = 0;
+    while ((1 << log_n) < n) log_n++;
+    LSA_REQUIRE(depth >= 1 && depth <= log_n, "bootstrap: linear-transform depth out of range");
+    const std::vector<int> rg = rot_group(n);
+    std::vector<int> lengths;
+    if (inverse)
+        for (int l = log_n; l >= 1; l--) lengths.push_back(1 << l);
+    else
+        for (int l = 1; l <= log_n; l++) lengths.push_back(1 << l);
+    std::vector<int> sizes;
+    int left = log_n;
+    for (int i = 0; i < depth; i++) {
+        const int s = (left + (depth - i) - 1) / (depth - i);
+        sizes.push_back(s);
+        left -= s;
+    }
+    if (!inverse) std::reverse(sizes.begin(), sizes.end());
+    std::vector<Diags> mats;
+    size_t pos = 0;
+    for (int s : sizes) {
+        Diags m;
+        for (int i = 0; i < s; i++) {
+            Diags lay = layer_diagonals(n, lengths[pos + i], inverse, rg);
+            m = i == 0 ? lay : compose(m, lay, n);
+        }
+        mats.push_back(std::move(m));
+        pos += s;
+    }
+    return mats;
+}
+
+void bsgs_sets(const std::vector<int>& ks, int n, int n1, std::vector<int>& giants, std::vector<int>& babies) {
+    std::map<int, bool> g, b;
+    for (int k : ks) {
+        g[((k % n) / n1) * n1 % n] = true;
+        b[(k % n) % n1] = true;
+    }
+    giants.clear();
+    babies.clear();
+    for (auto& kv : g) giants.push_back(kv.first);
+    for (auto& kv : b) babies.push_back(kv.first);
+}
+
+// the planner's baby-step count (frontend/bootstrap_params.py:193-207): the caller's Galois keys exist for this choice
+int bsgs_split(const std::vector<int>& ks, int n, double ratio) {
+    int n1 = 1;
+    std::vector<int> g, b;
+    while (n1 < n) {
+        bsgs_sets(ks, n, n1, g, b);
+        const int nb_g = (int)g.size() - 1, nb_b = (int)b.size() - 1;
+        if (nb_g == 0 || (double)nb_b / nb_g == ratio) return n1;
+        if ((double)nb_b / nb_g > ratio) return n1 / 2;
+        n1 <<= 1;
+    }
+    return 1;
+}
+
+// slots -> coefficients: t = U^-1 z (inverse special FFT), m_k = Re t_k, m_{k+n} = Im t_k
+std::vector<double> slots_to_coeffs(std::vector<cplx> v, const std::vector<int>& rg) {
+    const int n = (int)v.size();
+    const long long m = 4LL * n;
+    for (int len = n; len >= 2; len >>= 1) {
+        const int lenh = len >> 1;
+        const long long lenq = 4LL * len;
+        for (int i = 0; i < n; i += len)
+            for (int j = 0; j < lenh; j++) {
+                const long long idx = (lenq - (rg[j] % lenq)) * (m / lenq);
+                const cplx w = std::polar(1.0, 2.0 * kPi * (double)idx / (double)m);
+                const cplx a = v[i + j], b = v[i + j + lenh];
+                v[i + j] = a + b;
+                v[i + j + lenh] = (a - b) * w;
+            }
+    }
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    std::vector<double> out(2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        int r = 0;
+        for (int b = 0; b < lg; b++) r |= ((i >> b) & 1) << (lg - 1 - b);
+        out[i] = v[r].real() / n;
+        out[i + n] = v[r].imag() / n;
+    }
+    return out;
+}
+
+long long round_even(double v) { return (long long)std::nearbyint(v); }   // Python's round(): ties to even
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ plan
+struct BtMatrix {
+    int level = 0, n1 = 1;
+    bool naive = false;
+    std::vector<int> ks;                 // diagonal indices, ascending
+    std::vector<u64*> plains;            // per diagonal: NTT-domain plaintext [level+1][N] of rot_{-giant}(diag)
+};
+
+struct Bootstrap {
+    Context& c;
+    int cts_depth, stc_depth, K, r, top_level;
+    double mr, in_scale, out_scale;
+    std::vector<BtMatrix> cts, stc;
+    std::vector<double> cheb;            // 32 Chebyshev coefficients of cos(2 pi (K x - 1/4) / 2^r) on [-1,1]
+    u64* mono[2] = {nullptr, nullptr};   // NTT of +X^(N/2) and -X^(N/2), [top_level+1][N]
+    std::vector<u64> galois;             // Galois elements a run needs (rotations + conjugation)
+    long long mul_c = 1;                 // integer scale-up factor
+    double d1 = 0, natural_scale = 0;
+    std::vector<u64*> owned;
+
+    explicit Bootstrap(Context& ctx) : c(ctx) {}
+    ~Bootstrap() {
+        (void)hipSetDevice(c.device);
+        for (u64* p : owned) (void)hipFree(p);
+    }
+
+    RowMap rm_limbs(int L) const {
+        RowMap rm;
+        rm.period = L;
+        for (int j = 0; j < L; j++) rm.mod_of[j] = (unsigned char)j;
+        return rm;
+    }
+
+    // real polynomial coefficients * scale -> NTT-domain plaintext on the device
+    u64* upload_plain(const std::vector<double>& coef, double scale, int level, hipStream_t s) {
+        const int L = level + 1;
+        const size_t N = (size_t)c.n;
+        std::vector<u64> host((size_t)L * N);
+        for (size_t x = 0; x < N; x++) {
+            const long long v = round_even(coef[x] * scale);
+            for (int j = 0; j < L; j++) {
+                const long long q = (long long)c.T.mod[j];
+                long long r = v % q;
+                if (r < 0) r += q;
+                host[(size_t)j * N + x] = (u64)r;
+            }
+        }
+        u64* d = nullptr;
+        LSA_HIP(hipMalloc((void**)&d, host.size() * sizeof(u64)));
+        owned.push_back(d);
+        LSA_HIP(hipMemcpyAsync(d, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice, s));
+        launch_ntt(c, d, d, 1, (long long)L * N, L, rm_limbs(L), false, s);
+        LSA_HIP(hipStreamSynchronize(s));   // `host` goes out of scope
+        return d;
+    }
+
+    double evalmod_out_scale(int level_in) const {
+        int level = level_in - 5;
+        double sc = (double)c.T.mod[level + 1];
+        for (int i = 0; i < r; i++) {
+            sc = sc * sc / (double)c.T.mod[level];
+            level--;
+        }
+        return sc;
+    }
+
+    void build(hipStream_t s) {
+        const int n = c.n / 2;
+        top_level = c.nq - 1;
+        LSA_REQUIRE(c.algo == LSA_ALGO_CKKS, "bootstrap: CKKS only");
+        LSA_REQUIRE(top_level - cts_depth - 5 - r - stc_depth >= 0, "bootstrap: modulus chain too short");
+        const std::vector<int> rg = rot_group(n);
+        const double q0 = (double)c.T.mod[0];
+        mul_c = std::max<long long>(1, round_even(q0 / (mr * in_scale)));
+        d1 = in_scale * (double)mul_c;
+        const int evalmod_level = top_level - cts_depth;
+        const int stc_level = evalmod_level - 5 - r;
+        natural_scale = evalmod_out_scale(evalmod_level) * 2.0 * kPi * d1 / q0;
+        std::vector<Diags> mc = merged_matrices(n, cts_depth, true), ms = merged_matrices(n, stc_depth, false);
+        const double g = 1.0 / (2.0 * (double)n * (double)K);   // 1/n (inverse FFT), 1/2 (t + conj t), 1/K (unit interval)
+        for (auto& kv : mc[0])
+            for (auto& v : kv.second) v *= g;
+        if (out_scale > 0) {
+            const double kappa = out_scale / natural_scale;
+            for (auto& kv : ms[0])
+                for (auto& v : kv.second) v *= kappa;
+            natural_scale = out_scale;
+        }
+        std::map<u64, bool> gal;
+        auto gel = [&](int rot) {
+            u64 e = 1;
+            const u64 m = 2ULL * c.n;
+            for (int i = 0; i < rot % n; i++) e = e * 5 % m;
+            return e;
+        };
+        auto make = [&](std::vector<Diags>& mats, int level0, std::vector<BtMatrix>& out) {
+            for (size_t i = 0; i < mats.size(); i++) {
+                BtMatrix bm;
+                bm.level = level0 - (int)i;
+                for (auto& kv : mats[i]) bm.ks.push_back(kv.first);
+                bm.naive = bm.ks.size() < 3;
+                bm.n1 = bm.naive ? 1 : bsgs_split(bm.ks, n, 2.0);
+                const double pt_scale = (double)c.T.mod[bm.level];
+                for (int k : bm.ks) {
+                    const int giant = bm.naive ? 0 : (k / bm.n1) * bm.n1;
+                    const std::vector<cplx>& d = mats[i][k];
+                    std::vector<cplx> rolled(n);
+                    for (int t = 0; t < n; t++) rolled[t] = d[((t - giant) % n + n) % n];   // rot_{-giant}(diag)
+                    bm.plains.push_back(upload_plain(slots_to_coeffs(rolled, rg), pt_scale, bm.level, s));
+                    const int baby = bm.naive ? k : k - giant;
+                    if (baby) gal[gel(baby)] = true;
+                    if (giant) gal[gel(giant)] = true;
+                }
+                out.push_back(std::move(bm));
+            }
+        };
+        make(mc, top_level, cts);
+        make(ms, stc_level, stc);
+        gal[2ULL * c.n - 1] = true;
+        for (auto& kv : gal) galois.push_back(kv.first);
+        // Chebyshev interpolant (first-kind nodes) of cos(2 pi (K x - 1/4) / 2^r), 32 coefficients
+        const int M = 32;
+        cheb.assign(M, 0.0);
+        std::vector<double> f(M), th(M);
+        for (int j = 0; j < M; j++) {
+            th[j] = kPi * (j + 0.5) / M;
+            f[j] = std::cos(2.0 * kPi * ((double)K * std::cos(th[j]) - 0.25) / (double)(1 << r));
+        }
+        for (int k = 0; k < M; k++) {
+            double acc = 0;
+            for (int j = 0; j < M; j++) acc += f[j] * std::cos(k * th[j]);
+            cheb[k] = acc * (k == 0 ? 1.0 : 2.0) / M;
+        }
+        // monomials +-X^(N/2)  (times +-i on the slots)
+        for (int sg = 0; sg < 2; sg++) {
+            std::vector<double> xn2((size_t)c.n, 0.0);
+            xn2[c.n / 2] = sg == 0 ? 1.0 : -1.0;
+            mono[sg] = upload_plain(xn2, 1.0, top_level, s);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ device evaluator
+namespace {
+
+struct DBuf {
+    u64* p = nullptr;
+    size_t words = 0;
+    std::multimap<size_t, u64*>* pool;
+    ~DBuf() { pool->emplace(words, p); }
+};
+struct DCt {
+    std::shared_ptr<DBuf> buf;
+    int level = 0;
+    double scale = 0;
+    u64* data() const { return buf->p; }
+};
+
+struct Eval {
+    Context& c;
+    const Bootstrap& bt;
+    hipStream_t s;
+    int m;   // batch
+    const Key& rlk;
+    const std::map<u64, const Key*>& glk;
+    std::multimap<size_t, u64*> pool;   // released device buffers (single in-order stream: reuse is ordered)
+    std::vector<u64*> all;
+    long long N;
+
+    Eval(Context& c_, const Bootstrap& b, hipStream_t s_, int m_, const Key& rlk_, const std::map<u64, const Key*>& g)
+        : c(c_), bt(b), s(s_), m(m_), rlk(rlk_), glk(g), N(c_.n) {}
+    ~Eval() {
+        (void)hipStreamSynchronize(s);
+        for (u64* p : all) (void)hipFree(p);
+    }
+    long long stride(int level) const { return 2LL * (level + 1) * N; }
+    DCt alloc(int level, double scale) {
+        const size_t words = (size_t)m * stride(level);
+        auto b = std::make_shared<DBuf>();
+        b->words = words;
+        b->pool = &pool;
+        auto it = pool.find(words);
+        if (it != pool.end()) {
+            b->p = it->second;
+            pool.erase(it);
+        } else {
+            LSA_HIP(hipMalloc((void**)&b->p, words * sizeof(u64)));
+            all.push_back(b->p);
+        }
+        return DCt{b, level, scale};
+    }
+    RowMap rm2(int level) const {   // both polynomials' limbs
+        RowMap rm;
+        rm.period = level + 1;
+        for (int j = 0; j <= level; j++) rm.mod_of[j] = (unsigned char)j;
+        return rm;
+    }
+    double q(int level) const { return (double)c.T.mod[level]; }
+
+    DCt addsub(const DCt& a, const DCt& b, EwOp op) {
+        LSA_REQUIRE(a.level == b.level && std::fabs(a.scale / b.scale - 1) < 1e-9, "bootstrap: operands of add/sub differ in level or scale");
+        DCt o = alloc(a.level, a.scale);
+        launch_elementwise(c, op, a.data(), b.data(), o.data(), m, stride(a.level), stride(a.level), stride(a.level),
+                           2 * (a.level + 1), rm2(a.level), s);
+        return o;
+    }
+    DCt add(const DCt& a, const DCt& b) { return addsub(a, b, EW_ADD); }
+    DCt sub(const DCt& a, const DCt& b) { return addsub(a, b, EW_SUB); }
+    DCt drop(const DCt& a, int level) {
+        if (level == a.level) return a;
+        DCt o = alloc(level, a.scale);
+        std::vector<int> rows;
+        for (int p = 0; p < 2; p++)
+            for (int j = 0; j <= level; j++) rows.push_back(p * (a.level + 1) + j);
+        launch_copy_rows(c, a.data(), stride(a.level), o.data(), stride(level), (int)rows.size(), rows.data(), m, s);
+        return o;
+    }
+    DCt rescale(const DCt& a) {
+        DCt o = alloc(a.level - 1, a.scale / q(a.level));
+        ckks_rescale(c, a.level, 2, a.data(), o.data(), m, stride(a.level), stride(a.level - 1), s);
+        return o;
+    }
+    DCt mul(const DCt& a0, const DCt& b0) {
+        const int lvl = std::min(a0.level, b0.level);
+        DCt a = drop(a0, lvl), b = drop(b0, lvl);
+        DCt o = alloc(lvl - 1, a.scale * b.scale / q(lvl));
+        ckks_mult_relin_rescale(c, lvl, a.data(), b.data(), rlk, o.data(), m, stride(lvl), stride(lvl), stride(lvl - 1), s);
+        return o;
+    }
+    const Key& gkey(u64 e) const {
+        auto it = glk.find(e);
+        LSA_REQUIRE(it != glk.end(), "bootstrap: Galois key for element " + std::to_string(e) + " missing");
+        return *it->second;
+    }
+    DCt rotate(const DCt& a, int r) {
+        const int n = c.n / 2;
+        r = ((r % n) + n) % n;
+        if (r == 0) return a;
+        u64 e = 1;
+        for (int i = 0; i < r; i++) e = e * 5 % (2ULL * c.n);
+        DCt o = alloc(a.level, a.scale);
+        ckks_rotate(c, a.level, a.data(), e, gkey(e), o.data(), m, stride(a.level), stride(a.level), s);
+        return o;
+    }
+    DCt conj(const DCt& a) {
+        const u64 e = 2ULL * c.n - 1;
+        DCt o = alloc(a.level, a.scale);
+        ckks_rotate(c, a.level, a.data(), e, gkey(e), o.data(), m, stride(a.level), stride(a.level), s);
+        return o;
+    }
+    // per-limb constant vectors, cached on the context by value
+    const u64* kvec(long long k, int level, bool montgomery) {
+        std::vector<int> mods(level + 1);
+        std::vector<u64> vals(level + 1);
+        for (int j = 0; j <= level; j++) {
+            mods[j] = j;
+            const long long qq = (long long)c.T.mod[j];
+            long long r = k % qq;
+            if (r < 0) r += qq;
+            vals[j] = (u64)r;
+        }
+        const std::string name = std::string(montgomery ? "btm" : "btr") + std::to_string(level) + "_" + std::to_string(k);
+        return montgomery ? c.const_vec(name, mods, vals) : c.raw_vec(name, vals);
+    }
+    DCt mul_int_raw(const DCt& a, long long k, double new_scale) {
+        DCt o = alloc(a.level, new_scale);
+        unsigned char lm[LSA_MAX_PERIOD];
+        for (int j = 0; j <= a.level; j++) lm[j] = (unsigned char)j;
+        launch_sub_mul_general(c, 2, a.level + 1, lm, kvec(k, a.level, true), a.data(), stride(a.level), a.level + 1, nullptr, 0,
+                               0, nullptr, 0, 0, 0, o.data(), stride(a.level), a.level + 1, m, s);
+        return o;
+    }
+    DCt mul_int(const DCt& a, long long k) { return mul_int_raw(a, k, a.scale); }
+    DCt mul_const(const DCt& a, double cst, double const_scale) { return mul_int_raw(a, round_even(cst * const_scale), a.scale * const_scale); }
+    DCt add_const(const DCt& a, double cst) {
+        const long long k = round_even(cst * a.scale);
+        DCt o = alloc(a.level, a.scale);
+        LSA_HIP(hipMemcpyAsync(o.data(), a.data(), (size_t)m * stride(a.level) * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        launch_add_const(c, o.data(), stride(a.level), kvec(k, a.level, false), o.data(), stride(a.level), a.level + 1,
+                         rm2(a.level), m, s);
+        return o;
+    }
+    // every polynomial times a shared plaintext (stride 0 over the batch)
+    DCt mul_plain(const DCt& a, const u64* pt, double pt_scale) {
+        DCt o = alloc(a.level, a.scale * pt_scale);
+        const int L = a.level + 1;
+        for (int p = 0; p < 2; p++)
+            launch_elementwise(c, EW_MUL, a.data() + (size_t)p * L * N, pt, o.data() + (size_t)p * L * N, m, stride(a.level), 0,
+                               stride(a.level), L, rm2(a.level), s);
+        return o;
+    }
+    DCt mul_by_i(const DCt& a, int sign) { return mul_plain_keep_scale(a, bt.mono[sign > 0 ? 0 : 1]); }
+    DCt mul_plain_keep_scale(const DCt& a, const u64* pt) {
+        DCt o = mul_plain(a, pt, 1.0);
+        o.scale = a.scale;
+        return o;
+    }
+
+    DCt linear_transform(const DCt& ct, const BtMatrix& mt) {
+        LSA_REQUIRE(ct.level == mt.level, "bootstrap: linear transform applied at an unexpected level");
+        const double pt_scale = q(ct.level);
+        const int L = ct.level + 1;
+        std::map<int, DCt> babies;
+        auto baby = [&](int b) -> const DCt& {
+            auto it = babies.find(b);
+            if (it == babies.end()) it = babies.emplace(b, rotate(ct, b)).first;
+            return it->second;
+        };
+        // sum of (shared plaintext) x (rotated ciphertext) terms, LSA_MAC_MAX_TERMS per launch
+        auto mac = [&](const std::vector<std::pair<const u64*, const DCt*>>& terms) {
+            DCt o = alloc(ct.level, ct.scale * pt_scale);
+            for (size_t i0 = 0; i0 < terms.size(); i0 += LSA_MAC_MAX_TERMS) {
+                const int cnt = (int)std::min<size_t>(LSA_MAC_MAX_TERMS, terms.size() - i0);
+                const u64* cp[LSA_MAC_MAX_TERMS];
+                const u64* pp[LSA_MAC_MAX_TERMS];
+                long long cs[LSA_MAC_MAX_TERMS], ps[LSA_MAC_MAX_TERMS];
+                for (int i = 0; i < cnt; i++) {
+                    cp[i] = terms[i0 + i].second->data();
+                    cs[i] = stride(ct.level);
+                    pp[i] = terms[i0 + i].first;
+                    ps[i] = 0;
+                }
+                launch_mac_plain(c, cnt, cp, cs, pp, ps, i0 ? o.data() : nullptr, stride(ct.level), o.data(), stride(ct.level), m, 2,
+                                 L, rm2(ct.level), s);
+            }
+            return o;
+        };
+        DCt acc;
+        bool have = false;
+        if (mt.naive) {
+            std::vector<DCt> rots;
+            std::vector<std::pair<const u64*, const DCt*>> terms;
+            rots.reserve(mt.ks.size());
+            for (size_t i = 0; i < mt.ks.size(); i++) rots.push_back(rotate(ct, mt.ks[i]));
+            for (size_t i = 0; i < mt.ks.size(); i++) terms.push_back({mt.plains[i], &rots[i]});
+            acc = mac(terms);
+            return rescale(acc);
+        }
+        std::map<int, std::vector<size_t>> by_giant;
+        for (size_t i = 0; i < mt.ks.size(); i++) by_giant[(mt.ks[i] / mt.n1) * mt.n1].push_back(i);
+        for (auto& kv : by_giant) {
+            std::vector<std::pair<const u64*, const DCt*>> terms;
+            for (size_t i : kv.second) terms.push_back({mt.plains[i], &baby(mt.ks[i] - kv.first)});
+            DCt inner = rotate(mac(terms), kv.first);
+            acc = have ? add(acc, inner) : inner;
+            have = true;
+        }
+        return rescale(acc);
+    }
+
+    DCt eval_chebyshev(const DCt& u, const std::vector<double>& coeffs) {
+        int k = 0;
+        while ((1u << k) < coeffs.size()) k++;
+        std::map<int, DCt> powers;
+        powers[1] = u;
+        for (int j = 1; j < k; j++) {   // T_{2^j} = 2 T_{2^(j-1)}^2 - 1
+            const DCt& p = powers[1 << (j - 1)];
+            powers[1 << j] = add_const(mul_int(mul(p, p), 2), -1.0);
+        }
+        std::function<DCt(const std::vector<double>&, int, double)> rec = [&](const std::vector<double>& cf, int level_out,
+                                                                              double scale_out) -> DCt {
+            if (cf.size() == 2) {
+                DCt t1 = drop(u, level_out + 1);
+                const double cs = scale_out * q(level_out + 1) / t1.scale;
+                DCt rr = rescale(mul_const(t1, cf[1], cs));
+                rr.scale = scale_out;
+                return add_const(rr, cf[0]);
+            }
+            const size_t half = cf.size() / 2;
+            std::vector<double> hi(half, 0.0), lo(cf.begin(), cf.begin() + half);
+            hi[0] = cf[half];
+            for (size_t j = 1; j < half; j++) {   // T_{half+j} = 2 T_half T_j - T_{half-j}
+                hi[j] = 2 * cf[half + j];
+                lo[half - j] -= cf[half + j];
+            }
+            DCt th = drop(powers[(int)half], level_out + 1);
+            DCt h = rec(hi, level_out + 1, scale_out * q(level_out + 1) / th.scale);
+            DCt prod = mul(h, th);
+            prod.scale = scale_out;
+            return add(prod, rec(lo, level_out, scale_out));
+        };
+        const int level_out = u.level - k;
+        return rec(coeffs, level_out, q(level_out + 1));
+    }
+
+    DCt eval_mod(const DCt& u) {
+        DCt y = eval_chebyshev(u, bt.cheb);
+        for (int i = 0; i < bt.r; i++) y = add_const(mul_int(mul(y, y), 2), -1.0);
+        return y;
+    }
+
+    // level-0 ciphertext -> the same polynomials (centred mod q_0) over Q_top
+    DCt mod_raise(const DCt& a, int top) {
+        DCt o = alloc(top, q(0));
+        DCt tmp = alloc(0, a.scale);   // [m][2][1][N] coefficient-domain copy
+        RowMap r0;
+        r0.period = 1;
+        r0.mod_of[0] = 0;
+        launch_ntt(c, a.data(), tmp.data(), m, stride(0), stride(0), 2, r0, true, s);
+        // each polynomial is one "ring-t plaintext": centred lift from q_0 to every limb, then NTT
+        launch_lift_ringt(c, 0, top, tmp.data(), N, o.data(), (long long)(top + 1) * N, 2 * m, s);
+        launch_ntt(c, o.data(), o.data(), m, stride(top), 2 * (top + 1), rm2(top), false, s);
+        return o;
+    }
+};
+
+}  // namespace
+
+Bootstrap* bootstrap_create(Context& c, int cts_depth, int stc_depth, int K, int double_angle, double message_ratio,
+                            double in_scale, double out_scale, hipStream_t s) {
+    auto b = std::make_unique<Bootstrap>(c);
+    b->cts_depth = cts_depth;
+    b->stc_depth = stc_depth;
+    b->K = K;
+    b->r = double_angle;
+    b->mr = message_ratio;
+    b->in_scale = in_scale;
+    b->out_scale = out_scale;
+    c.use_device();
+    b->build(s);
+    return b.release();
+}
+void bootstrap_destroy(Bootstrap* b) { delete b; }
+
+// in: [batch][2][1][N] level-0 ciphertexts at the plan's input scale; out: [batch][2][out_level+1][N]
+void bootstrap_run(Bootstrap& bt, const u64* in, long long sin, u64* out, long long sout, int batch, const Key& rlk,
+                   const std::map<u64, const Key*>& glk, const Key* swk_dts, const Key* swk_std, hipStream_t s) {
+    Context& c = bt.c;
+    c.use_device();
+    Eval ev(c, bt, s, batch, rlk, glk);
+    const long long N = c.n;
+    // diagnostic: LSA_BT_STOP=<step> returns the first out_level+1 limbs of that step's intermediate instead
+    const char* stop_env = getenv("LSA_BT_STOP");
+    const int stop = stop_env ? atoi(stop_env) : -1;
+    const int out_level = bootstrap_out_level(bt);
+    int step = 0;
+    auto emit = [&](const DCt& v) {
+        std::vector<int> rr;
+        const int lv = std::min(v.level, out_level);
+        for (int p = 0; p < 2; p++)
+            for (int j = 0; j <= out_level; j++) rr.push_back(p * (v.level + 1) + std::min(j, lv));
+        launch_copy_rows(c, v.data(), ev.stride(v.level), out, sout, (int)rr.size(), rr.data(), batch, s);
+    };
+#define LSA_BT_CHECK(v)            \
+    if (++step == stop) {          \
+        emit(v);                   \
+        return;                    \
+    }
+    DCt x = ev.alloc(0, bt.in_scale);
+    std::vector<int> rows = {0, 1};
+    launch_copy_rows(c, in, sin, x.data(), 2 * N, 2, rows.data(), batch, s);
+    x = ev.mul_int(x, bt.mul_c);
+    LSA_BT_CHECK(x)   // 1
+    if (swk_dts) {
+        DCt y = ev.alloc(0, x.scale);
+        ckks_switch_key(c, 0, x.data(), *swk_dts, y.data(), batch, 2 * N, 2 * N, s);
+        x = y;
+    }
+    x = ev.mod_raise(x, bt.top_level);
+    LSA_BT_CHECK(x)   // 2
+    if (swk_std) {
+        DCt y = ev.alloc(bt.top_level, x.scale);
+        ckks_switch_key(c, bt.top_level, x.data(), *swk_std, y.data(), batch, ev.stride(bt.top_level), ev.stride(bt.top_level), s);
+        x = y;
+    }
+    for (auto& mt : bt.cts) {
+        x = ev.linear_transform(x, mt);
+        LSA_BT_CHECK(x)   // 3 .. 2+cts_depth
+    }
+    DCt xc = ev.conj(x);
+    DCt u_re = ev.add(x, xc);
+    LSA_BT_CHECK(u_re)
+    DCt u_im = ev.mul_by_i(ev.sub(x, xc), -1);
+    LSA_BT_CHECK(u_im)
+    DCt y_re = ev.eval_mod(u_re);
+    LSA_BT_CHECK(y_re)
+    DCt y_im = ev.eval_mod(u_im);
+    DCt y = ev.add(y_re, ev.mul_by_i(y_im, 1));
+    LSA_BT_CHECK(y)
+    for (auto& mt : bt.stc) y = ev.linear_transform(y, mt);
+#undef LSA_BT_CHECK
+    std::vector<int> all(2 * (y.level + 1));
+    for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
+    launch_copy_rows(c, y.data(), ev.stride(y.level), out, sout, (int)all.size(), all.data(), batch, s);
+}
+
+int bootstrap_out_level(const Bootstrap& bt) { return bt.top_level - bt.cts_depth - 5 - bt.r - bt.stc_depth; }
+
+// read-only views for the C API (constants are exported so that the oracle can replay the program with the same integers)
+double bootstrap_out_scale(const Bootstrap& bt) { return bt.natural_scale; }
+const std::vector<u64>& bootstrap_galois(const Bootstrap& bt) { return bt.galois; }
+const std::vector<double>& bootstrap_chebyshev(const Bootstrap& bt) { return bt.cheb; }
+int bootstrap_matrices(const Bootstrap& bt) { return (int)(bt.cts.size() + bt.stc.size()); }
+int bootstrap_cts_matrices(const Bootstrap& bt) { return (int)bt.cts.size(); }
+void bootstrap_matrix(const Bootstrap& bt, int i, int* level, int* n1, const std::vector<int>** ks, const std::vector<u64*>** plains) {
+    LSA_REQUIRE(i >= 0 && i < bootstrap_matrices(bt), "bootstrap: matrix index out of range");
+    const BtMatrix& m = i < (int)bt.cts.size() ? bt.cts[i] : bt.stc[i - bt.cts.size()];
+    *level = m.level;
+    *n1 = m.naive ? 0 : m.n1;
+    *ks = &m.ks;
+    *plains = &m.plains;
+}
+
+}  // namespace lsa

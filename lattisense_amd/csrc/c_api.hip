@@ -342,6 +342,94 @@ int lsa_debug_set_ntt_stamps(lsa_context ctx, void* device_buffer) {
     return guard([&] { C(ctx).ntt_diag = static_cast<unsigned long long*>(device_buffer); });
 }
 
+// ---- CKKS bootstrapping
+struct lsa_bootstrap_st {
+    Bootstrap* b;
+    Context* c;
+};
+int lsa_bootstrap_create(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
+                         double in_scale, double out_scale, void* stream, lsa_bootstrap* out) {
+    return guard([&] {
+        LSA_REQUIRE(out != nullptr, "null argument");
+        LSA_REQUIRE(k >= 1 && double_angle >= 0 && double_angle <= 8 && message_ratio > 0 && in_scale > 0, "bad bootstrap parameters");
+        auto h = std::make_unique<lsa_bootstrap_st>();
+        h->c = &C(ctx);
+        h->b = bootstrap_create(C(ctx), cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale, S(stream));
+        *out = h.release();
+    });
+}
+void lsa_bootstrap_destroy(lsa_bootstrap b) {
+    if (!b) return;
+    bootstrap_destroy(b->b);
+    delete b;
+}
+int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* n_galois, int* n_matrices, int* n_cts) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr, "null bootstrap handle");
+        if (out_level) *out_level = bootstrap_out_level(*b->b);
+        if (out_scale) *out_scale = bootstrap_out_scale(*b->b);
+        if (n_galois) *n_galois = (int)bootstrap_galois(*b->b).size();
+        if (n_matrices) *n_matrices = bootstrap_matrices(*b->b);
+        if (n_cts) *n_cts = bootstrap_cts_matrices(*b->b);
+    });
+}
+int lsa_bootstrap_galois_elements(lsa_bootstrap b, uint64_t* out, int capacity) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr && out != nullptr, "null argument");
+        const auto& g = bootstrap_galois(*b->b);
+        LSA_REQUIRE((int)g.size() <= capacity, "buffer too small");
+        for (size_t i = 0; i < g.size(); i++) out[i] = g[i];
+    });
+}
+int lsa_bootstrap_chebyshev(lsa_bootstrap b, double* out32) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr && out32 != nullptr, "null argument");
+        const auto& cf = bootstrap_chebyshev(*b->b);
+        for (size_t i = 0; i < cf.size(); i++) out32[i] = cf[i];
+    });
+}
+int lsa_bootstrap_matrix_info(lsa_bootstrap b, int index, int* level, int* n1, int* n_diagonals, int* diagonals, int capacity) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr, "null bootstrap handle");
+        int lv, n1v;
+        const std::vector<int>* ks;
+        const std::vector<u64*>* pl;
+        bootstrap_matrix(*b->b, index, &lv, &n1v, &ks, &pl);
+        if (level) *level = lv;
+        if (n1) *n1 = n1v;
+        if (n_diagonals) *n_diagonals = (int)ks->size();
+        if (diagonals) {
+            LSA_REQUIRE((int)ks->size() <= capacity, "buffer too small");
+            for (size_t i = 0; i < ks->size(); i++) diagonals[i] = (*ks)[i];
+        }
+    });
+}
+int lsa_bootstrap_plaintext(lsa_bootstrap b, int matrix, int diag_pos, uint64_t* host_out) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr && host_out != nullptr, "null argument");
+        int lv, n1v;
+        const std::vector<int>* ks;
+        const std::vector<u64*>* pl;
+        bootstrap_matrix(*b->b, matrix, &lv, &n1v, &ks, &pl);
+        LSA_REQUIRE(diag_pos >= 0 && diag_pos < (int)pl->size(), "diagonal position out of range");
+        b->c->use_device();
+        LSA_HIP(hipMemcpy(host_out, (*pl)[diag_pos], (size_t)(lv + 1) * b->c->n * sizeof(u64), hipMemcpyDeviceToHost));
+    });
+}
+int lsa_ckks_bootstrap(lsa_context ctx, lsa_bootstrap b, const uint64_t* in, uint64_t* out, int batch, long long sin, long long sout,
+                       lsa_key rlk, int n_glk, const uint64_t* glk_elements, const lsa_key* glk, lsa_key swk_dts, lsa_key swk_std,
+                       void* stream) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr && in != nullptr && out != nullptr && rlk != nullptr, "null argument");
+        LSA_REQUIRE(b->c == &C(ctx), "bootstrap plan belongs to another context");
+        LSA_REQUIRE((swk_dts == nullptr) == (swk_std == nullptr), "swk_dts and swk_std come as a pair");
+        std::map<u64, const Key*> g;
+        for (int i = 0; i < n_glk; i++) g[glk_elements[i]] = &K(glk[i]);
+        bootstrap_run(*b->b, in, sin, out, sout, batch, K(rlk), g, swk_dts ? &K(swk_dts) : nullptr,
+                      swk_std ? &K(swk_std) : nullptr, S(stream));
+    });
+}
+
 int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib) {
     return guard([&] {
         LSA_REQUIRE(mib >= 0, "chunk size must be >= 0");

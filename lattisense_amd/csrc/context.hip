@@ -278,4 +278,16 @@ const u64* Context::const_vec(const std::string& name, const std::vector<int>& m
     return d;
 }
 
+const u64* Context::raw_vec(const std::string& name, const std::vector<u64>& vals) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = consts.find(name);
+    if (it != consts.end()) return it->second;
+    use_device();
+    u64* d = nullptr;
+    LSA_HIP(hipMalloc((void**)&d, vals.size() * sizeof(u64)));
+    LSA_HIP(hipMemcpy(d, vals.data(), vals.size() * sizeof(u64), hipMemcpyHostToDevice));
+    consts[name] = d;
+    return d;
+}
+
 }  // namespace lsa

@@ -293,6 +293,44 @@ void launch_muladd(Context& c, EwOp op, const u64* a, const u64* b, const u64* a
     LSA_HIP(hipGetLastError());
 }
 
+// out[b][row] = a[b][row] + kvec[row]: a real constant added to every slot is the same residue in every NTT coefficient of c0
+struct AddConstArgs {
+    const u64* a;
+    u64* out;
+    const u64* kvec;   // per row, plain residues
+    long long sa, so;
+    const ModDev* mods;
+    int logn;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+__global__ __launch_bounds__(TPB) void k_add_const(AddConstArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const u64 q = g.mods[g.mod_of[row]].q, k = g.kvec[row];
+    const long long b = blockIdx.y, off = ((long long)row << g.logn) + x;
+    const ulonglong2 v = ld2(g.a + b * g.sa + off);
+    st2(g.out + b * g.so + off, add_mod(v.x, k, q), add_mod(v.y, k, q));
+}
+void launch_add_const(Context& c, const u64* a, long long sa, const u64* kvec, u64* out, long long so, int rows,
+                      const RowMap& rm, int batch, hipStream_t s) {
+    if (batch <= 0 || rows <= 0) return;
+    LSA_REQUIRE(rm.period == rows && rows <= LSA_MAX_PERIOD, "add_const: row map must cover the rows");
+    AddConstArgs g{};
+    g.a = a;
+    g.out = out;
+    g.kvec = kvec;
+    g.sa = sa;
+    g.so = so;
+    g.mods = c.d_mods;
+    g.logn = c.logn;
+    int period;
+    fill_rowmap(g.mod_of, period, rm, c.nmod);
+    ProfScope ps(c, PROF_ELEMWISE, 16.0 * c.n * rows * batch, s);
+    hipLaunchKernelGGL(k_add_const, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
 // ciphertext x plaintext multiply-accumulate over up to LSA_MAC_MAX_TERMS terms in ONE launch (cmp_sum / cmpac_sum nodes,
 // mega_ag_executors_gpu.cu:294-408 does multiply_plain + add_inplace per term):
 //   out[p][j] = (partial[p][j]) + sum_i ct_i[p][j] * pt_i[j]

@@ -130,6 +130,7 @@ struct Context {
     const u32* coeff_perm(u64 g);
     // per-modulus constant vector on device, Montgomery form, built by `gen(mod_index)`
     const u64* const_vec(const std::string& name, const std::vector<int>& mods, const std::vector<u64>& plain_vals);
+    const u64* raw_vec(const std::string& name, const std::vector<u64>& vals);   // cached device copy, no conversion
 };
 
 // RAII sample of one kernel launch: records an event pair around every prof_stride-th launch of a kind
@@ -254,8 +255,26 @@ void launch_sub_mul_const(Context& c, const u64* a, long long sa, const u64* b, 
                           long long so, int rows, const RowMap& rm, int batch, hipStream_t s);
 void launch_mul_const(Context& c, const u64* a, long long sa, const u64* kvec, u64* out, long long so, int rows,
                       const RowMap& rm, int batch, hipStream_t s);
+// out[row] = a[row] + kvec[row] (plain residues, one per row)
+void launch_add_const(Context& c, const u64* a, long long sa, const u64* kvec, u64* out, long long so, int rows,
+                      const RowMap& rm, int batch, hipStream_t s);
 void launch_probe_copy(u64* dst, const u64* src, size_t n, hipStream_t s);
 void launch_probe_mulhi(u64* buf, size_t n, int iters, hipStream_t s);
+
+// ---------------------------------------------------------------- CKKS bootstrapping (bootstrap.hip)
+struct Bootstrap;
+Bootstrap* bootstrap_create(Context& c, int cts_depth, int stc_depth, int K, int double_angle, double message_ratio,
+                            double in_scale, double out_scale, hipStream_t s);
+void bootstrap_destroy(Bootstrap* b);
+int bootstrap_out_level(const Bootstrap& bt);
+double bootstrap_out_scale(const Bootstrap& bt);
+const std::vector<u64>& bootstrap_galois(const Bootstrap& bt);
+const std::vector<double>& bootstrap_chebyshev(const Bootstrap& bt);
+int bootstrap_matrices(const Bootstrap& bt);
+int bootstrap_cts_matrices(const Bootstrap& bt);
+void bootstrap_matrix(const Bootstrap& bt, int i, int* level, int* n1, const std::vector<int>** ks, const std::vector<u64*>** plains);
+void bootstrap_run(Bootstrap& bt, const u64* in, long long sin, u64* out, long long sout, int batch, const Key& rlk,
+                   const std::map<u64, const Key*>& glk, const Key* swk_dts, const Key* swk_std, hipStream_t s);
 
 // ---------------------------------------------------------------- operator pipelines (ops.hip)
 const std::string& last_error();

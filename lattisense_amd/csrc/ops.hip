@@ -304,6 +304,18 @@ void ckks_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u6
     });
 }
 
+// (c0, c1) under s_in -> (c0 + ks0, ks1) under s_out with a generic switching key (bootstrapping's sparse-secret
+// encapsulation keys swk_dts / swk_std, reference: custom_task.py:1989-1996): the rotation pipeline without the permutation
+void ckks_switch_key(Context& c, int level, const u64* in, const Key& swk, u64* out, int batch, long long sin, long long sout,
+                     hipStream_t s) {
+    const long long N = c.n;
+    const int L = level + 1;
+    for_tiles(c, ks_ws_rows(c, level), batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
+        const u64* ct = in + (size_t)b0 * sin;
+        key_switch(c, level, ct + (long long)L * N, sin, swk, out + (size_t)b0 * sout, sout, ct, sin, L, 1, nb, ws, st);
+    });
+}
+
 void ckks_mult_relin_rescale(Context& c, int level, const u64* a, const u64* b, const Key& rlk, u64* out, int batch,
                              long long sa, long long sb, long long so, hipStream_t s) {
     LSA_REQUIRE(level >= 1, "mult+relin+rescale needs level >= 1");

@@ -198,3 +198,55 @@ class DeviceContext:
         check(lib().lsa_bfv_mult_relin(self.h, level, a.ptr, b.ptr, rlk, out.ptr, batch, 2 * L * self.n,
                                        2 * L * self.n, 2 * L * self.n, self.stream))
         return out
+
+
+class BootstrapPlan:
+    """Device-side CKKS bootstrapping plan (include/lattisense_amd.h: lsa_bootstrap_*)."""
+
+    def __init__(self, ctx, cts_depth=4, stc_depth=3, k=16, double_angle=3, message_ratio=256.0, in_scale=2.0 ** 40,
+                 out_scale=0.0):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        check(lib().lsa_bootstrap_create(ctx.h, cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale,
+                                         ctx.stream, ctypes.byref(h)))
+        self.h = h
+        lv, sc, ng, nm, nc = ctypes.c_int(), ctypes.c_double(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().lsa_bootstrap_info(self.h, ctypes.byref(lv), ctypes.byref(sc), ctypes.byref(ng), ctypes.byref(nm),
+                                       ctypes.byref(nc)))
+        self.out_level, self.out_scale, self.n_matrices, self.n_cts = lv.value, sc.value, nm.value, nc.value
+        g = (ctypes.c_uint64 * ng.value)()
+        check(lib().lsa_bootstrap_galois_elements(self.h, g, ng.value))
+        self.galois_elements = [int(x) for x in g]
+
+    def close(self):
+        if self.h:
+            lib().lsa_bootstrap_destroy(self.h)
+            self.h = None
+
+    def chebyshev(self):
+        out = (ctypes.c_double * 32)()
+        check(lib().lsa_bootstrap_chebyshev(self.h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def matrix(self, index):
+        """(level, n1 (0: no baby-step/giant-step), diagonal indices, {k: plaintext [level+1][N]})"""
+        lv, n1, nd = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().lsa_bootstrap_matrix_info(self.h, index, ctypes.byref(lv), ctypes.byref(n1), ctypes.byref(nd), None, 0))
+        ks = (ctypes.c_int * nd.value)()
+        check(lib().lsa_bootstrap_matrix_info(self.h, index, None, None, None, ks, nd.value))
+        plains = {}
+        for i, k in enumerate(ks):
+            pt = np.empty((lv.value + 1, self.ctx.n), dtype=np.uint64)
+            check(lib().lsa_bootstrap_plaintext(self.h, index, i, pt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+            plains[int(k)] = pt
+        return lv.value, n1.value, [int(k) for k in ks], plains
+
+    def run(self, in_buf, batch, rlk, glk, swk_dts=None, swk_std=None):
+        """in_buf: device [batch][2][1][N]; glk: {galois element: key handle}; returns device [batch][2][out_level+1][N]"""
+        n = self.ctx.n
+        out = self.ctx.alloc(batch * 2 * (self.out_level + 1) * n)
+        elts = (ctypes.c_uint64 * len(glk))(*glk.keys())
+        keys = (ctypes.c_void_p * len(glk))(*[k.value for k in glk.values()])
+        check(lib().lsa_ckks_bootstrap(self.ctx.h, self.h, in_buf.ptr, out.ptr, batch, 2 * n, 2 * (self.out_level + 1) * n, rlk,
+                                       len(glk), elts, keys, swk_dts, swk_std, self.ctx.stream))
+        return out

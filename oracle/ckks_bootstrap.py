@@ -233,18 +233,21 @@ def rotations_of(diags, n_slots, ratio=2.0):
     return sorted({r for r in giants + babies if r})
 
 
-def linear_transform(ev, ct, diags, ratio=2.0):
+def linear_transform(ev, ct, diags, ratio=2.0, plains=None):
     """ct <- M ct for M in diagonal form; the diagonals are encoded at the scale of the ciphertext's top prime, so the single
     rescale at the end leaves the scale unchanged.  Consumes one level.  Fewer than three diagonals: one rotation each;
     otherwise baby-step / giant-step with the planner's split:
         M x = sum_g rot_g( sum_b rot_{-g}(d_{g+b}) . rot_b(x) )."""
+    # `plains`: {k: NTT-domain plaintext [level+1][N]} replaces this module's own encoding of (rot_{-g} of) diagonal k --
+    # the parity tests pass the device library's plaintexts so that both sides multiply by the same integers
     n = ev.n // 2
     ks = sorted(diags)
     pt_scale = float(ev.q(ct.level))
     acc = None
     if len(ks) < 3:
         for k in ks:
-            term = ev.mul_plain(ev.rotate(ct, k), ev.encode(diags[k], ct.level, pt_scale), pt_scale)
+            pt = plains[k] if plains is not None else ev.encode(diags[k], ct.level, pt_scale)
+            term = ev.mul_plain(ev.rotate(ct, k), pt, pt_scale)
             acc = term if acc is None else ev.add(acc, term)
         return ev.rescale(acc)
     n1 = bsgs_split(ks, n, ratio)
@@ -258,7 +261,7 @@ def linear_transform(ev, ct, diags, ratio=2.0):
             b = k - g
             if b not in babies:
                 babies[b] = ev.rotate(ct, b)
-            pt = ev.encode(np.roll(diags[k], g), ct.level, pt_scale)     # rot_{-g}(diag)
+            pt = plains[k] if plains is not None else ev.encode(np.roll(diags[k], g), ct.level, pt_scale)   # rot_{-g}(diag)
             term = ev.mul_plain(babies[b], pt, pt_scale)
             inner = term if inner is None else ev.add(inner, term)
         inner = ev.rotate(inner, g)
@@ -307,11 +310,12 @@ def eval_chebyshev(ev, u, coeffs):
     return rec(np.asarray(coeffs, dtype=np.float64), level_out, float(ev.q(level_out + 1)))
 
 
-def eval_mod(ev, u, K, double_angle):
+def eval_mod(ev, u, K, double_angle, coeffs=None):
     """u = v/K with v = I + eps (I integer, |I| < K, |eps| small) -> sin(2 pi v) ~ 2 pi eps, via the Chebyshev interpolant of
     cos(2 pi (K u - 1/4) / 2^r) on [-1, 1] (31 coefficients) and r double-angle steps y <- 2 y^2 - 1."""
     r = double_angle
-    coeffs = chebyshev_coeffs(lambda x: np.cos(2 * np.pi * (K * x - 0.25) / (1 << r)), 31)
+    if coeffs is None:
+        coeffs = chebyshev_coeffs(lambda x: np.cos(2 * np.pi * (K * x - 0.25) / (1 << r)), 31)
     y = eval_chebyshev(ev, u, coeffs)
     for _ in range(r):
         sq = ev.mul(y, y)
@@ -321,8 +325,12 @@ def eval_mod(ev, u, K, double_angle):
 
 # ------------------------------------------------------------------------------------------------ bootstrap
 class Bootstrapper:
-    def __init__(self, ev, cts_depth=4, stc_depth=3, K=16, double_angle=3, message_ratio=256.0, out_scale=None):
+    def __init__(self, ev, cts_depth=4, stc_depth=3, K=16, double_angle=3, message_ratio=256.0, out_scale=None,
+                 plains=None, coeffs=None):
+        """plains: {("cts"|"stc", matrix index): {k: plaintext}} and coeffs (32 Chebyshev coefficients) override this
+        module's own floating-point constants with another implementation's (see linear_transform)."""
         self.ev = ev
+        self.plains, self.coeffs = plains, coeffs
         self.n = ev.n // 2
         self.K, self.r, self.mr = K, double_angle, message_ratio
         self.cts_depth, self.stc_depth = cts_depth, stc_depth
@@ -381,14 +389,14 @@ class Bootstrapper:
         if swk_std is not None:
             x = self.key_switch(x, swk_std, top_level)
         # 3. CoeffsToSlots -> packed coefficients t / (2K) in bit-reversed order
-        for m in self.cts:
-            x = linear_transform(ev, x, m)
+        for i, m in enumerate(self.cts):
+            x = linear_transform(ev, x, m, plains=self.plains[("cts", i)] if self.plains else None)
         xc = ev.conj(x)
         u_re = ev.add(x, xc)                                   # Re(t)/K
         u_im = ev.mul_by_i(ev.sub(x, xc), -1)                  # Im(t)/K
         # 4. EvalMod on both halves: sin(2 pi v) ~ 2 pi d1 m_k / q0
-        y_re = eval_mod(ev, u_re, self.K, self.r)
-        y_im = eval_mod(ev, u_im, self.K, self.r)
+        y_re = eval_mod(ev, u_re, self.K, self.r, self.coeffs)
+        y_im = eval_mod(ev, u_im, self.K, self.r, self.coeffs)
         y = ev.add(y_re, ev.mul_by_i(y_im, 1))
         # 5. SlotsToCoeffs.  The slots then hold (2 pi d1 / q0) * z at scale y.scale, i.e. z at scale y.scale * 2 pi d1 / q0;
         #    a requested output scale is met by folding the ratio into the first matrix (the caller pre-sets the scale on
@@ -400,6 +408,6 @@ class Bootstrapper:
             kappa = self.out_scale / natural
             stc[0] = {k: d * kappa for k, d in stc[0].items()}
             natural = self.out_scale
-        for m in stc:
-            y = linear_transform(ev, y, m)
+        for i, m in enumerate(stc):
+            y = linear_transform(ev, y, m, plains=self.plains[("stc", i)] if self.plains else None)
         return Ct(y.data, y.level, natural)

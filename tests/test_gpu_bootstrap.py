@@ -1,0 +1,73 @@
+"""CKKS bootstrapping on the device (lattisense_amd/csrc/bootstrap.hip, the `bootstrap` node of a task graph) against its
+oracle (oracle/ckks_bootstrap.py): the device plan's floating-point constants (encoded diagonals, Chebyshev coefficients) are
+fed to the oracle program, after which every step is integer arithmetic on both sides -- the refreshed ciphertext must be
+identical bit for bit -- and the reference's own assertion (mean precision >= 10 bits, unittests/test_gpu_ckks.cpp:763-781)
+is applied to the device result."""
+import numpy as np
+import pytest
+
+from tests.gpu_util import need_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(log_n, hamming, seed):
+    from lattisense_amd import params
+    from lattisense_amd.device import ALGO_CKKS, DeviceContext
+    from oracle.client import Client
+    from oracle.pyoracle import Oracle
+    B = params.CKKS_BOOTSTRAP_65536       # the reference's bootstrap chain: 25 Q + 5 P (custom_task.py:387-420)
+    N = 1 << log_n
+    o = Oracle(N, B["q"], B["p"], 0)
+    c = Client(o, seed=seed, hamming=hamming)
+    ctx = DeviceContext(ALGO_CKKS, N, B["q"], B["p"])
+    return B, N, o, c, ctx
+
+
+def _oracle_plains(plan):
+    plains = {}
+    for i in range(plan.n_matrices):
+        _, _, _, pts = plan.matrix(i)
+        plains[("cts", i) if i < plan.n_cts else ("stc", i - plan.n_cts)] = pts
+    return plains
+
+
+@pytest.mark.parametrize("log_n,encapsulate", [(10, False), (11, True)])
+def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate):
+    need_gpu()
+    from lattisense_amd.device import BootstrapPlan
+    from oracle.ckks_bootstrap import Bootstrapper, Ct, Evaluator
+    from oracle.client import Client, mean_precision_bits
+    B, N, o, c, ctx = _setup(log_n, None if encapsulate else 32, 11 + log_n)
+    top = len(B["q"]) - 1
+    D = float(2 ** 40)
+    plan = BootstrapPlan(ctx, in_scale=D, out_scale=D)
+    assert plan.out_level == 9 and plan.out_scale == D          # btp_output_level, parameter scale
+    ev = Evaluator(o, c, top)
+    rlk = ctx.upload_key(ev.rlk, top)
+    keys = {e: c.gen_galois_key(e, top) for e in plan.galois_elements}
+    ev.glk = dict(keys)          # both sides rotate with the same keys (freshly generated ones differ in their noise)
+    glk = {e: ctx.upload_key(k, top) for e, k in keys.items()}
+    dts = std = kd = ks = None
+    if encapsulate:
+        sparse = Client(o, seed=99, hamming=32)
+        dts = c.gen_switching_key(c.s_ntt, sparse.s_ntt, 0)
+        std = c.gen_switching_key(sparse.s_ntt, c.s_ntt, top)
+        kd, ks = ctx.upload_key(dts, 0), ctx.upload_key(std, top)
+    rng = np.random.default_rng(log_n)
+    batch = 2
+    zs = [rng.uniform(-1, 1, N // 2) + 1j * rng.uniform(-1, 1, N // 2) for _ in range(batch)]
+    cts = np.stack([c.ckks_encrypt(z, 0, D) for z in zs])          # [batch][2][1][N]
+    out = plan.run(ctx.upload(cts), batch, rlk, glk, kd, ks)
+    got = ctx.download(out, (batch, 2, plan.out_level + 1, N))
+    # the oracle program with the device plan's constants
+    bt = Bootstrapper(ev, out_scale=D, plains=_oracle_plains(plan), coeffs=plan.chebyshev())
+    for b in range(batch):
+        want = bt.bootstrap(Ct(cts[b], 0, D), top, dts, std)
+        assert want.level == plan.out_level and want.scale == D
+        assert np.array_equal(got[b], want.data)
+        re, im = mean_precision_bits(zs[b], c.ckks_decrypt(got[b], D))
+        assert re >= 10 and im >= 10
+    # the oracle program needed no key beyond the ones the device plan listed (the reference planner's rotations + conjugation)
+    assert sorted(ev.glk) == sorted(plan.galois_elements)
+    plan.close()
