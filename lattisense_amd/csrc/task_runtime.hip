@@ -240,7 +240,10 @@ void bind_gpu_executor(ComputeNode& node, Algo algorithm) {
                 throw std::runtime_error("Multiply with plaintext only supported for CKKS scheme");  // executors_gpu.cu:349,405
             break;
         }
-        case OperationType::BOOTSTRAP: unsupported("bootstrapping is scheduled for a later round"); break;
+        case OperationType::BOOTSTRAP:   // inputs [ct, rlk, glk..., swk_dts, swk_std] (frontend/custom_task.py:1952-2002)
+            if (algorithm != ALGO_CKKS) throw std::runtime_error("BOOTSTRAP only supported for CKKS scheme");  // executors_gpu.cu:424
+            if (node.input_nodes.size() < 5) unsupported("bootstrap node without its keys");
+            break;
         default: unsupported("unknown");
     }
 }
@@ -263,6 +266,34 @@ struct fhe_task_handle_st {
     std::vector<std::shared_ptr<Slab>>& pending_free() { return pending_free_[cur_lane]; }
     int last_gpu_nodes = 0, last_gpu_batches = 0;
     double last_ms = 0;
+    struct BtDeleter {
+        void operator()(Bootstrap* b) const { bootstrap_destroy(b); }
+    };
+    std::map<Context*, std::unique_ptr<Bootstrap, BtDeleter>> bootstrap_plans;   // built on first use, per lane context
+
+    // bootstrapping plan from the task's `parameter` block (reference: gpu_wrapper.cu:86-117)
+    Bootstrap& bootstrap_plan(Context& c, hipStream_t s) {
+        auto it = bootstrap_plans.find(&c);
+        if (it != bootstrap_plans.end()) return *it->second;
+        const mjson::Value& P = g.parameter;
+        LSA_REQUIRE(P.contains("btp_output_level"), "bootstrap node in a task without bootstrapping parameters");
+        LSA_REQUIRE(P["btp_eval_mod_sine_type"].as_string() == "Cos1" && P["btp_eval_mod_arcsine_deg"].as_int() == 0,
+                    "bootstrap: only the Cos1 sine type without arcsine is implemented");
+        LSA_REQUIRE(!P.contains("slots") || P["slots"].as_int() == c.n / 2, "bootstrap: only full-slot encoding is implemented");
+        LSA_REQUIRE(P["btp_eval_mod_sine_deg"].as_int() <= 31, "bootstrap: sine degree above 31 is not implemented");
+        const int cts_depth = (int)P["btp_cts_depth"].as_int(), stc_depth = (int)P["btp_stc_depth"].as_int();
+        LSA_REQUIRE(P["btp_cts_start_level"].as_int() == c.nq - 1 && P["btp_eval_mod_start_level"].as_int() == c.nq - 1 - cts_depth,
+                    "bootstrap: level plan differs from the one implemented");
+        const double scale = P["scale"].as_double();
+        Bootstrap* b = bootstrap_create(c, cts_depth, stc_depth, (int)P["btp_eval_mod_k"].as_int(),
+                                        (int)P["btp_eval_mod_double_angle"].as_int(), P["btp_eval_mod_message_ratio"].as_double(),
+                                        scale, scale, s);
+        LSA_REQUIRE(bootstrap_out_level(*b) == P["btp_output_level"].as_int() &&
+                        P["btp_stc_start_level"].as_int() == bootstrap_out_level(*b) + stc_depth,
+                    "bootstrap: level plan differs from the one implemented");
+        bootstrap_plans[&c].reset(b);
+        return *b;
+    }
 
     explicit fhe_task_handle_st(const std::string& project_path) {
         g = TaskGraph::load_for_gpu(project_path + "/mega_ag.json");
@@ -768,6 +799,26 @@ struct fhe_task_handle_st {
                 const int kpos = (int)n0->input_nodes.size() - 1;
                 Operand b = kpos == 1 ? a : gather(c, s, nodes, 1, avail, w_in);
                 ckks_mult_relin_rescale(c, lvl, a.ptr, b.ptr, key_of(kpos), out, m, a.stride, b.stride, so, s);
+                break;
+            }
+            case OperationType::BOOTSTRAP: {
+                LSA_REQUIRE(!bfv && polys_in == 2 && lvl == 0, "bootstrap expects a degree-1 CKKS ciphertext at level 0");
+                Bootstrap& plan = bootstrap_plan(c, s);
+                LSA_REQUIRE(out_lvl == bootstrap_out_level(plan), "bootstrap: output datum is not at the bootstrap output level");
+                std::map<u64, const Key*> glk;
+                std::vector<const Key*> swk;
+                for (size_t i = 2; i < n0->input_nodes.size(); i++) {
+                    const DatumNode* kd = n0->input_nodes[i];
+                    if (kd->datum_type == TYPE_GALOIS_KEY) {
+                        LSA_REQUIRE(kd->fhe_prop && kd->fhe_prop->p, "Galois element missing on the key datum");
+                        glk[kd->fhe_prop->p->galois_element] = &key_of((int)i);
+                    } else if (kd->datum_type == TYPE_SWITCH_KEY) {
+                        swk.push_back(&key_of((int)i));
+                    }
+                }
+                LSA_REQUIRE(swk.empty() || swk.size() == 2, "bootstrap: swk_dts and swk_std come as a pair");
+                bootstrap_run(plan, a.ptr, a.stride, out, so, m, key_of(1), glk, swk.empty() ? nullptr : swk[0],
+                              swk.empty() ? nullptr : swk[1], s);
                 break;
             }
             case OperationType::RELINEARIZE:

@@ -71,3 +71,55 @@ def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate):
     # the oracle program needed no key beyond the ones the device plan listed (the reference planner's rotations + conjugation)
     assert sorted(ev.glk) == sorted(plan.galois_elements)
     plan.close()
+
+
+def test_bootstrap_node_through_the_task_boundary():
+    """A task compiled by the reference's frontend from its toy bootstrap parameter set (ring reduced to N=2048 for the CPU
+    oracle): one `bootstrap` node per ciphertext, keys rlk / 22 column rotations / conjugation / swk_dts / swk_std as the
+    frontend lists them.  Through run_fhe_gpu_task: level 0 -> 9, >= 10 bits, and identical to the oracle program fed with the
+    constants of an operator-level plan built from the same parameters."""
+    need_gpu()
+    import json
+    import os
+    from lattisense_amd.device import ALGO_CKKS, BootstrapPlan, DeviceContext
+    from lattisense_amd.task import Argument, Ciphertext, FheTaskGpu, GaloisKey, KeySwitchKey
+    from oracle.ckks_bootstrap import Bootstrapper, Ct, Evaluator
+    from oracle.client import Client, mean_precision_bits
+    from oracle.pyoracle import Oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "tasks", "ckks_n2048_bootstrap")
+    P = json.load(open(os.path.join(path, "mega_ag.json")))["parameter"]
+    sig = json.load(open(os.path.join(path, "task_signature.json")))
+    n, q, p, D = P["n"], P["q"], P["p"], float(P["scale"])
+    top, k = len(q) - 1, len(p)
+    o = Oracle(n, q, p, 0)
+    c, sparse = Client(o, seed=41), Client(o, seed=42, hamming=32)      # dense main secret, sparse ephemeral secret
+    ev = Evaluator(o, c, top)
+    keys = {int(e): c.gen_galois_key(int(e), top) for e in sig["key"]["glk"]}
+    ev.glk = dict(keys)
+    dts = c.gen_switching_key(c.s_ntt, sparse.s_ntt, 0)
+    std = c.gen_switching_key(sparse.s_ntt, c.s_ntt, top)
+    rng = np.random.default_rng(43)
+    zs = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(2)]
+    cts = [c.ckks_encrypt(z, 0, D) for z in zs]
+    t = FheTaskGpu(path)
+    ys = [Ciphertext.empty(1, P["btp_output_level"], n) for _ in range(2)]
+    t.run([Argument("in_x_list", [Ciphertext(x) for x in cts]), Argument("rlk_ntt", [KeySwitchKey(ev.rlk, top, k)]),
+           Argument("glk_ntt", [GaloisKey({e: KeySwitchKey(kk, top, k) for e, kk in keys.items()})]),
+           Argument("swk_dts", [KeySwitchKey(dts, 0, k)]), Argument("swk_std", [KeySwitchKey(std, top, k)])],
+          [Argument("out_y_list", ys)])
+    assert t.last_run_stats()["gpu_batches"] == 1                       # both bootstraps in one batched program
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    plan = BootstrapPlan(ctx, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
+                         P["btp_eval_mod_message_ratio"], D, D)
+    plains = {}
+    for i in range(plan.n_matrices):
+        plains[("cts", i) if i < plan.n_cts else ("stc", i - plan.n_cts)] = plan.matrix(i)[3]
+    bt = Bootstrapper(ev, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
+                      P["btp_eval_mod_message_ratio"], out_scale=D, plains=plains, coeffs=plan.chebyshev())
+    for i in range(2):
+        re, im = mean_precision_bits(zs[i], c.ckks_decrypt(ys[i].data, D))
+        assert re >= 10 and im >= 10
+        assert np.array_equal(ys[i].data, bt.bootstrap(Ct(cts[i], 0, D), top, dts, std).data)
+    plan.close()
+    t.close()

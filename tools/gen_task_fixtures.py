@@ -144,6 +144,16 @@ def main():
     ys = [rotate_rows(xs[i], f"y_{i}") for i in range(N_OP)]
     emit("bfv_n4096_rotate_row", [Argument("xs", xs)], [Argument("ys", ys)])
 
+    # CKKS bootstrapping: the reference's toy bootstrap parameter set (custom_task.py:284-380: 25+5 primes, CtS depth 4,
+    # Cos1 K=16 deg 30 with 3 double angles, StC depth 3, output level 9) on a ring small enough for the CPU oracle
+    bp = CkksBtpParam.create_toy_param()
+    bp.n = 2048
+    bp.slots = 1024
+    set_fhe_param(bp)
+    xs = [CkksCiphertextNode(f"x_{i}", level=0) for i in range(2)]
+    ys = [bootstrap(xs[i], f"y_{i}") for i in range(2)]
+    emit("ckks_n2048_bootstrap", [Argument("in_x_list", xs)], [Argument("out_y_list", ys)])
+
     # application-shaped graph: packed conv2d, 1 -> 1 channels of 32x32, 3x3 kernel (two channel slots per ciphertext at N=4096)
     conv_fixture("ckks_n4096_conv2d_1in_1out_32x32_3x3", ckks_param(4096, 5), 4096, 1, 1, (32, 32), (3, 3), 2)
 
