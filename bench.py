@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep", "deep17", "task_ckks", "task_bfv", "task_conv"])
+    ap.add_argument("--workload", default="ckks_hmult", choices=["ckks_hmult", "ntt", "rotate", "bfv_hmult", "deep", "deep17", "task_ckks", "task_bfv", "task_conv", "bootstrap"])
     ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU (0 = workload default)")
     ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
     ap.add_argument("--ntt-chunk-mib", type=int, default=-1, help="Infinity-Cache chunk of two-pass NTTs (-1 = default)")
@@ -177,8 +177,99 @@ def run_conv_workload(args):
         "roofline": None, "cpu_baseline": None}), flush=True)
 
 
+def run_bootstrap_workload(args):
+    """CKKS bootstrapping at the reference's default bootstrap parameter set (N=2^16, 25 Q + 5 P primes, CtS depth 4, Cos1
+    K=16 degree 30 with 3 double angles, StC depth 3, level 0 -> 9; frontend/custom_task.py:383-468), device-resident
+    synthetic inputs and keys (the relinearisation key, one Galois key per planner rotation + conjugation, swk_dts / swk_std).
+    A step bootstraps `batch` ciphertexts in one batched program."""
+    import ctypes
+    import torch
+    from lattisense_amd import params
+    from lattisense_amd._native import check, lib
+    from lattisense_amd.device import ALGO_CKKS, BootstrapPlan, DeviceContext
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B = params.CKKS_BOOTSTRAP_65536
+    n, q, p = 1 << 16, B["q"], B["p"]
+    top, np_ = len(q) - 1, len(p)
+    batch = args.batch or 4
+    ctx = DeviceContext(ALGO_CKKS, n, q, p, 0, device=local_rank)
+    ctx.stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L_ = lib()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+
+    def uniform(shape_prefix, mods):
+        out = torch.empty(*shape_prefix, len(mods), n, dtype=torch.int64, device=dev)
+        for i, m in enumerate(mods):
+            out[..., i, :] = torch.randint(0, m, (*shape_prefix, n), dtype=torch.int64, device=dev, generator=gen)
+        return out
+
+    t0 = time.perf_counter()
+    plan = BootstrapPlan(ctx, in_scale=2.0 ** 40, out_scale=2.0 ** 40)
+    t_plan = time.perf_counter() - t0
+    keep = []
+
+    def key(level):
+        beta = (level + 1 + np_ - 1) // np_
+        t = uniform((beta, 2), q[: level + 1] + p)
+        keep.append(t)
+        return ctx.adopt_key(t.data_ptr(), level)
+
+    rlk = key(top)
+    glk = {e: key(top) for e in plan.galois_elements}
+    dts, std = key(0), key(top)
+    x = uniform((batch, 2), q[:1])
+
+    class Buf:
+        def __init__(self, t):
+            self.t, self.ptr = t, t.data_ptr()
+
+    def step():
+        return plan.run(Buf(x), batch, rlk, glk, dts, std)
+
+    for _ in range(args.warmup):
+        step().free()
+    torch.cuda.synchronize()
+    check(L_.lsa_profile_begin(ctx.h, args.prof_stride))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step().free()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    check(L_.lsa_profile_end(ctx.h))
+    kinds = {0: "k_ntt_pass", 1: "k_baseconv", 2: "k_ks_mac", 3: "k_tensor", 4: "elementwise"}
+    breakdown = {}
+    for kid, name in kinds.items():
+        ms, by = ctypes.c_double(), ctypes.c_double()
+        ns, nl = ctypes.c_longlong(), ctypes.c_longlong()
+        check(L_.lsa_profile_read(ctx.h, kid, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(ns), ctypes.byref(nl)))
+        if ns.value:
+            breakdown[name] = {"est_ms_per_step": ms.value / ns.value * nl.value / args.steps, "avg_launch_us": ms.value / ns.value * 1e3,
+                               "achieved_GBps": by.value / ms.value / 1e6, "launches_per_step": nl.value / args.steps}
+    ntt = breakdown.get("k_ntt_pass")
+    roofline = None
+    if ntt:
+        roofline = {"kernel": "k_ntt_pass", "bound": "hbm", "achieved": ntt["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ntt["achieved_GBps"] / HBM_PEAK_GBPS, "traffic": None, "avg_launch_us": ntt["avg_launch_us"],
+                    "launches_per_step": ntt["launches_per_step"]}
+    print(json.dumps({
+        "metric": "ckks_bootstrap_throughput", "value": batch * args.steps / dt, "unit": "bootstraps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "CKKS bootstrap N=2^16 25Q+5P (N16QP1546H192H32), level 0 -> %d" % plan.out_level,
+                   "batch_per_gpu": batch, "galois_keys": len(glk), "key_bytes_total": sum(t.numel() * 8 for t in keep),
+                   "plan_build_s": t_plan, "ms_per_bootstrap": dt / args.steps / batch * 1e3},
+        "roofline": roofline, "cpu_baseline": None, "kernel_breakdown": breakdown}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "bootstrap":
+        return run_bootstrap_workload(args)
     if args.workload == "task_conv":
         return run_conv_workload(args)
     if args.workload.startswith("task_"):

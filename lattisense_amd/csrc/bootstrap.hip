@@ -212,11 +212,17 @@ struct Bootstrap {
     long long mul_c = 1;                 // integer scale-up factor
     double d1 = 0, natural_scale = 0;
     std::vector<u64*> owned;
+    // temporaries of a run, kept across runs (hipMalloc / hipFree of GiB-sized buffers cost more than the kernels); a plan
+    // belongs to one context and is run on one in-order stream at a time, so reuse is ordered
+    std::multimap<size_t, u64*> pool;
+    std::vector<u64*> pool_all;
 
     explicit Bootstrap(Context& ctx) : c(ctx) {}
     ~Bootstrap() {
         (void)hipSetDevice(c.device);
+        (void)hipDeviceSynchronize();
         for (u64* p : owned) (void)hipFree(p);
+        for (u64* p : pool_all) (void)hipFree(p);
     }
 
     RowMap rm_limbs(int L) const {
@@ -353,21 +359,16 @@ struct DCt {
 
 struct Eval {
     Context& c;
-    const Bootstrap& bt;
+    Bootstrap& bt;
     hipStream_t s;
     int m;   // batch
     const Key& rlk;
     const std::map<u64, const Key*>& glk;
-    std::multimap<size_t, u64*> pool;   // released device buffers (single in-order stream: reuse is ordered)
-    std::vector<u64*> all;
+    std::multimap<size_t, u64*>& pool;   // released device buffers (single in-order stream: reuse is ordered)
     long long N;
 
-    Eval(Context& c_, const Bootstrap& b, hipStream_t s_, int m_, const Key& rlk_, const std::map<u64, const Key*>& g)
-        : c(c_), bt(b), s(s_), m(m_), rlk(rlk_), glk(g), N(c_.n) {}
-    ~Eval() {
-        (void)hipStreamSynchronize(s);
-        for (u64* p : all) (void)hipFree(p);
-    }
+    Eval(Context& c_, Bootstrap& b, hipStream_t s_, int m_, const Key& rlk_, const std::map<u64, const Key*>& g)
+        : c(c_), bt(b), s(s_), m(m_), rlk(rlk_), glk(g), pool(b.pool), N(c_.n) {}
     long long stride(int level) const { return 2LL * (level + 1) * N; }
     DCt alloc(int level, double scale) {
         const size_t words = (size_t)m * stride(level);
@@ -380,7 +381,7 @@ struct Eval {
             pool.erase(it);
         } else {
             LSA_HIP(hipMalloc((void**)&b->p, words * sizeof(u64)));
-            all.push_back(b->p);
+            bt.pool_all.push_back(b->p);
         }
         return DCt{b, level, scale};
     }
