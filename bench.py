@@ -195,7 +195,7 @@ def run_bootstrap_workload(args):
     B = params.CKKS_BOOTSTRAP_65536
     n, q, p = 1 << 16, B["q"], B["p"]
     top, np_ = len(q) - 1, len(p)
-    batch = args.batch or 4
+    batch = args.batch or 16
     ctx = DeviceContext(ALGO_CKKS, n, q, p, 0, device=local_rank)
     ctx.stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     L_ = lib()

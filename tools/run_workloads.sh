@@ -4,7 +4,7 @@ TAG=${1:-run}
 OUT=gpurun_out/workloads_$TAG.log
 : > $OUT
 python bench.py 2> gpurun_out/err_ckks_hmult.log >> $OUT || exit 1
-for w in rotate bfv_hmult deep deep17 ntt task_ckks task_bfv task_conv; do
+for w in rotate bfv_hmult deep deep17 ntt task_ckks task_bfv task_conv bootstrap; do
   python bench.py --workload $w --no-cpu-baseline 2> gpurun_out/err_$w.log >> $OUT || exit 1
 done
 python - "$OUT" <<'PY'
