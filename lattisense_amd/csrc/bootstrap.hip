@@ -26,6 +26,8 @@ namespace lsa {
 void ckks_rescale(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
 void ckks_rotate(Context&, int, const u64*, u64, const Key&, u64*, int, long long, long long, hipStream_t);
 void ckks_switch_key(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
+void ckks_rotate_many(Context&, int, const u64*, int, const u64*, const Key* const*, u64* const*, int, long long, long long,
+                      hipStream_t);
 void ckks_mult_relin_rescale(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long, long long,
                              hipStream_t);
 
@@ -438,6 +440,32 @@ struct Eval {
         ckks_rotate(c, a.level, a.data(), e, gkey(e), o.data(), m, stride(a.level), stride(a.level), s);
         return o;
     }
+    // rotations of one ciphertext by several steps with a single decomposition (hoisted); same residues as rotate()
+    std::map<int, DCt> rotate_many(const DCt& a, const std::vector<int>& steps) {
+        const int n = c.n / 2;
+        std::map<int, DCt> out;
+        std::vector<u64> els;
+        std::vector<const Key*> keys;
+        std::vector<u64*> ptrs;
+        for (int r0 : steps) {
+            const int r = ((r0 % n) + n) % n;
+            if (out.count(r)) continue;
+            if (r == 0) {
+                out[0] = a;
+                continue;
+            }
+            u64 e = 1;
+            for (int i = 0; i < r; i++) e = e * 5 % (2ULL * c.n);
+            DCt o = alloc(a.level, a.scale);
+            els.push_back(e);
+            keys.push_back(&gkey(e));
+            ptrs.push_back(o.data());
+            out[r] = o;
+        }
+        ckks_rotate_many(c, a.level, a.data(), (int)els.size(), els.data(), keys.data(), ptrs.data(), m, stride(a.level),
+                         stride(a.level), s);
+        return out;
+    }
     DCt conj(const DCt& a) {
         const u64 e = 2ULL * c.n - 1;
         DCt o = alloc(a.level, a.scale);
@@ -496,12 +524,11 @@ struct Eval {
         LSA_REQUIRE(ct.level == mt.level, "bootstrap: linear transform applied at an unexpected level");
         const double pt_scale = q(ct.level);
         const int L = ct.level + 1;
-        std::map<int, DCt> babies;
-        auto baby = [&](int b) -> const DCt& {
-            auto it = babies.find(b);
-            if (it == babies.end()) it = babies.emplace(b, rotate(ct, b)).first;
-            return it->second;
-        };
+        // every baby step is a rotation of the SAME ciphertext: one decomposition serves them all
+        std::vector<int> steps;
+        for (int k : mt.ks) steps.push_back(mt.naive ? k : k % mt.n1);
+        std::map<int, DCt> babies = rotate_many(ct, steps);
+        auto baby = [&](int b) -> const DCt& { return babies.at(b); };
         // sum of (shared plaintext) x (rotated ciphertext) terms, LSA_MAC_MAX_TERMS per launch
         auto mac = [&](const std::vector<std::pair<const u64*, const DCt*>>& terms) {
             DCt o = alloc(ct.level, ct.scale * pt_scale);
@@ -524,11 +551,8 @@ struct Eval {
         DCt acc;
         bool have = false;
         if (mt.naive) {
-            std::vector<DCt> rots;
             std::vector<std::pair<const u64*, const DCt*>> terms;
-            rots.reserve(mt.ks.size());
-            for (size_t i = 0; i < mt.ks.size(); i++) rots.push_back(rotate(ct, mt.ks[i]));
-            for (size_t i = 0; i < mt.ks.size(); i++) terms.push_back({mt.plains[i], &rots[i]});
+            for (size_t i = 0; i < mt.ks.size(); i++) terms.push_back({mt.plains[i], &baby(mt.ks[i])});
             acc = mac(terms);
             return rescale(acc);
         }

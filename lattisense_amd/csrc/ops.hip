@@ -40,18 +40,20 @@ struct KsRescale {
 
 // p[h][i] = (h < base_polys ? base[h][i] : 0) + ModDown( sum_d ModUp_d(cx) * key_d[h] )[i]   (all NTT domain)
 // With `rs` (needs fused tails): p is scratch of the same shape and rs->out receives rescale(p).
-static void key_switch(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
-                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
-                       const KsRescale* rs = nullptr) {
+static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
+                      const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
+                      const KsRescale* rs);
+
+// steps 1-3: cx out of the NTT domain, every digit converted to the other limbs of Q u P, extended limbs back into the
+// NTT domain (workspace layout: cxi | ext | acc | conv)
+static void ks_decompose(Context& c, int level, const u64* cx, long long scx, int nb, u64* ws, hipStream_t s) {
     LSA_REQUIRE(c.np >= 1, "key switching needs at least one special prime");
     LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
     const long long N = c.n;
     const int L = level + 1, np = c.np, T = L + np, beta = ceil_div(L, np);
     u64* cxi = ws;
     u64* ext = cxi + (size_t)nb * L * N;
-    u64* acc = ext + (size_t)nb * beta * T * N;
-    u64* conv = acc + (size_t)nb * 2 * T * N;
-    const long long s_cxi = (long long)L * N, s_ext = (long long)beta * T * N, s_acc = 2LL * T * N, s_conv = 2LL * L * N;
+    const long long s_cxi = (long long)L * N, s_ext = (long long)beta * T * N;
 
     // 1. cx out of the NTT domain
     launch_ntt(c, cx, cxi, nb, scx, s_cxi, L, rm_seq(L), true, s);
@@ -93,6 +95,21 @@ static void key_switch(Context& c, int level, const u64* cx, long long scx, cons
             launch_ntt(c, ext + (size_t)d * T * N, ext + (size_t)d * T * N, nb, s_ext, T, rm, false, s);
         }
     }
+}
+
+// steps 4-5 of a key switch on the digits that ks_decompose left in the workspace: they depend on the key, the decomposition
+// does not -- rotations of ONE ciphertext by several Galois elements share it ("hoisting"; with the automorphism applied
+// after the switch, as here, every rotation's residues are the same as if it had been computed on its own)
+static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
+                      const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
+                      const KsRescale* rs) {
+    const long long N = c.n;
+    const int L = level + 1, np = c.np, T = L + np, beta = ceil_div(L, np);
+    u64* cxi = ws;
+    u64* ext = cxi + (size_t)nb * L * N;
+    u64* acc = ext + (size_t)nb * beta * T * N;
+    u64* conv = acc + (size_t)nb * 2 * T * N;
+    const long long s_ext = (long long)beta * T * N, s_acc = 2LL * T * N, s_conv = 2LL * L * N;
     // 4. gadget inner product with the key (both halves)
     launch_ks_mac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s);
     // 5. ModDown: P-part out of NTT, centred exact conversion P -> Q, back to NTT, (accQ - conv) * P^-1 (+ base)
@@ -183,6 +200,13 @@ static void key_switch(Context& c, int level, const u64* cx, long long scx, cons
         launch_ntt(c, conv, conv, nb, s_conv, 2 * L, rm_seq(L), false, s);
         launch_moddown_final(c, level, acc, s_acc, T, conv, s_conv, base, sbase, base_rpp, base_polys, p, sp, nb, s);
     }
+}
+
+static void key_switch(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
+                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
+                       const KsRescale* rs = nullptr) {
+    ks_decompose(c, level, cx, scx, nb, ws, s);
+    ks_finish(c, level, cx, scx, key, p, sp, base, sbase, base_rpp, base_polys, nb, ws, s, rs);
 }
 
 // ------------------------------------------------------------------------------------------------ rescale
@@ -301,6 +325,28 @@ void ckks_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u6
         const u64* ct = in + (size_t)b0 * sin;
         key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, ct, sin, L, 1, nb, ws, st);
         launch_permute_ntt(c, perm, p, sp, out + (size_t)b0 * sout, sout, 2 * L, nb, st);
+    });
+}
+
+// rotations of the same ciphertexts by several Galois elements with ONE decomposition (hoisting); outs[i] = rotate(in, g[i]),
+// each identical to ckks_rotate's result
+void ckks_rotate_many(Context& c, int level, const u64* in, int n_rot, const u64* g, const Key* const* glk, u64* const* outs,
+                      int batch, long long sin, long long sout, hipStream_t s) {
+    if (n_rot <= 0) return;
+    const long long N = c.n;
+    const int L = level + 1;
+    const size_t ks_rows = ks_ws_rows(c, level);
+    const long long sp = 2LL * L * N;
+    std::vector<const u32*> perms(n_rot);
+    for (int i = 0; i < n_rot; i++) perms[i] = c.ntt_perm(g[i]);
+    for_tiles(c, ks_rows + 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
+        u64* p = ws + ks_rows * N * tb;
+        const u64* ct = in + (size_t)b0 * sin;
+        ks_decompose(c, level, ct + (long long)L * N, sin, nb, ws, st);
+        for (int i = 0; i < n_rot; i++) {
+            ks_finish(c, level, ct + (long long)L * N, sin, *glk[i], p, sp, ct, sin, L, 1, nb, ws, st, nullptr);
+            launch_permute_ntt(c, perms[i], p, sp, outs[i] + (size_t)b0 * sout, sout, 2 * L, nb, st);
+        }
     });
 }
 
