@@ -233,24 +233,27 @@ def rotations_of(diags, n_slots, ratio=2.0):
     return sorted({r for r in giants + babies if r})
 
 
-def linear_transform(ev, ct, diags, ratio=2.0, plains=None):
+def linear_transform(ev, ct, diags, ratio=2.0, plains=None, rescale=True, n_slots=None):
     """ct <- M ct for M in diagonal form; the diagonals are encoded at the scale of the ciphertext's top prime, so the single
     rescale at the end leaves the scale unchanged.  Consumes one level.  Fewer than three diagonals: one rotation each;
     otherwise baby-step / giant-step with the planner's split:
         M x = sum_g rot_g( sum_b rot_{-g}(d_{g+b}) . rot_b(x) )."""
     # `plains`: {k: NTT-domain plaintext [level+1][N]} replaces this module's own encoding of (rot_{-g} of) diagonal k --
     # the parity tests pass the device library's plaintexts so that both sides multiply by the same integers
+    # n_slots: period of the diagonals (sparse packing: shorter than N/2; they are tiled over the N/2 slots when encoded)
     n = ev.n // 2
+    period = n_slots or n
+    tile = (lambda v: np.tile(v, n // len(v)))
     ks = sorted(diags)
     pt_scale = float(ev.q(ct.level))
     acc = None
     if len(ks) < 3:
         for k in ks:
-            pt = plains[k] if plains is not None else ev.encode(diags[k], ct.level, pt_scale)
+            pt = plains[k] if plains is not None else ev.encode(tile(diags[k]), ct.level, pt_scale)
             term = ev.mul_plain(ev.rotate(ct, k), pt, pt_scale)
             acc = term if acc is None else ev.add(acc, term)
-        return ev.rescale(acc)
-    n1 = bsgs_split(ks, n, ratio)
+        return ev.rescale(acc) if rescale else acc
+    n1 = bsgs_split(ks, period, ratio)
     babies = {}
     by_giant = {}
     for k in ks:
@@ -261,12 +264,12 @@ def linear_transform(ev, ct, diags, ratio=2.0, plains=None):
             b = k - g
             if b not in babies:
                 babies[b] = ev.rotate(ct, b)
-            pt = plains[k] if plains is not None else ev.encode(np.roll(diags[k], g), ct.level, pt_scale)   # rot_{-g}(diag)
+            pt = plains[k] if plains is not None else ev.encode(tile(np.roll(diags[k], g)), ct.level, pt_scale)   # rot_{-g}(diag)
             term = ev.mul_plain(babies[b], pt, pt_scale)
             inner = term if inner is None else ev.add(inner, term)
         inner = ev.rotate(inner, g)
         acc = inner if acc is None else ev.add(acc, inner)
-    return ev.rescale(acc)
+    return ev.rescale(acc) if rescale else acc
 
 
 # ------------------------------------------------------------------------------------------------ EvalMod
@@ -410,4 +413,98 @@ class Bootstrapper:
             natural = self.out_scale
         for i, m in enumerate(stc):
             y = linear_transform(ev, y, m, plains=self.plains[("stc", i)] if self.plains else None)
+        return Ct(y.data, y.level, natural)
+
+
+class SparseBootstrapper(Bootstrapper):
+    """Sparse packing: 2^log_slots < N/2 slots (the reference also tests log_slots = 11 at N = 2^16, unittests/fixture.hpp:
+    152-162).  The plaintext lives in the subring of X^gap (gap = (N/2)/slots), its slot vector has period `slots`.
+      SubSum: ct += rot_{2^i}(ct), i = log_slots .. logN-2 -- the trace onto the subring: the integer polynomial I of the
+        raised ciphertext loses its coefficients off the subring, the rest is multiplied by gap (folded into CoeffsToSlots);
+      CoeffsToSlots on `slots` points; the last matrix M is applied as  y = P1 x + P2 conj(x)  with diagonals of period
+        2*slots: first half Re(Mx) = (M x + conj(M) conj(x))/2, second half Im(Mx) = (-i M x + i conj(M) conj(x))/2, so ONE
+        EvalMod serves both coefficient halves ("repack imag to real", frontend/bootstrap_params.py:74);
+      SlotsToCoeffs: first matrix = (first group of forward layers) o R with the two-diagonal repack R = {0, slots}
+        (bootstrap_params.py:233, :121-133): t[k] = y[k] + i y[k+slots]."""
+
+    def __init__(self, ev, log_slots, cts_depth=4, stc_depth=3, K=16, double_angle=3, message_ratio=256.0, out_scale=None,
+                 plains=None, coeffs=None):
+        """plains keys: ("cts", i) for the leading matrices, ("p1",), ("p2",), ("stc", i)"""
+        self.ev = ev
+        self.plains, self.coeffs = plains, coeffs
+        self.n = ev.n // 2
+        self.ns = ns = 1 << log_slots
+        self.log_slots = log_slots
+        assert ns < self.n
+        self.K, self.r, self.mr = K, double_angle, message_ratio
+        self.out_scale = out_scale
+        gap = self.n // ns
+        cts = merged_matrices(ns, cts_depth, inverse=True)
+        last = cts.pop()
+        half = lambda a, b: np.concatenate([a, b])
+        self.p1 = {k: half(0.5 * d, -0.5j * d) for k, d in last.items()}
+        self.p2 = {k: half(0.5 * np.conj(d), 0.5j * np.conj(d)) for k, d in last.items()}
+        g = 1.0 / (ns * gap * K)              # 1/slots (inverse FFT), 1/gap (SubSum), 1/K (unit interval)
+        if cts:
+            cts[0] = {k: d * g for k, d in cts[0].items()}
+        else:
+            self.p1 = {k: d * g for k, d in self.p1.items()}
+            self.p2 = {k: d * g for k, d in self.p2.items()}
+        self.cts = cts
+        # SlotsToCoeffs: forward layers on `slots` points, grouped as for the dense case; the first group is preceded by R
+        log_ns = log_slots
+        lengths = [1 << l for l in range(1, log_ns + 1)]
+        sizes, left = [], log_ns
+        for i in range(stc_depth):
+            sz = -(-left // (stc_depth - i))
+            sizes.append(sz)
+            left -= sz
+        sizes = sizes[::-1]
+        ones, eye = np.ones(ns), 1j * np.ones(ns)
+        m = {0: half(ones, eye), ns: half(eye, ones)}          # R on period 2*slots
+        mats, pos = [], 0
+        for gi, sz in enumerate(sizes):
+            for length in lengths[pos: pos + sz]:
+                lay = layer_diagonals(ns, length, False)
+                if gi == 0:
+                    lay = {k: np.tile(d, 2) for k, d in lay.items()}
+                    m = compose(m, lay, 2 * ns)
+                else:
+                    m = lay if m is None else compose(m, lay, ns)
+            mats.append(m)
+            m = None
+            pos += sz
+        self.stc = mats
+
+    def bootstrap(self, ct, top_level, swk_dts=None, swk_std=None):
+        ev = self.ev
+        ns = self.ns
+        assert ct.level == 0
+        q0 = ev.q(0)
+        c = max(1, int(round(q0 / (self.mr * ct.scale))))
+        d1 = ct.scale * c
+        ct = ev.mul_int(ct, c)
+        if swk_dts is not None:
+            ct = self.key_switch(ct, swk_dts, 0)
+        x = Ct(self.mod_raise(ct, top_level), top_level, float(q0))
+        if swk_std is not None:
+            x = self.key_switch(x, swk_std, top_level)
+        for i in range(self.log_slots, ev.n.bit_length() - 2):          # SubSum
+            x = ev.add(x, ev.rotate(x, 1 << i))
+        pl = self.plains or {}
+        for i, m in enumerate(self.cts):
+            x = linear_transform(ev, x, m, n_slots=ns, plains=pl.get(("cts", i)))
+        a = linear_transform(ev, x, self.p1, rescale=False, n_slots=2 * ns, plains=pl.get(("p1",)))
+        b = linear_transform(ev, ev.conj(x), self.p2, rescale=False, n_slots=2 * ns, plains=pl.get(("p2",)))
+        u = ev.rescale(ev.add(a, b))                                    # [Re(t)/K | Im(t)/K], period 2*slots
+        y = eval_mod(ev, u, self.K, self.r, self.coeffs)
+        natural = y.scale * 2 * np.pi * d1 / q0
+        stc = list(self.stc)
+        if self.out_scale is not None:
+            kappa = self.out_scale / natural
+            stc[0] = {k: d * kappa for k, d in stc[0].items()}
+            natural = self.out_scale
+        y = linear_transform(ev, y, stc[0], n_slots=2 * ns, plains=pl.get(("stc", 0)))
+        for i, m in enumerate(stc[1:], 1):
+            y = linear_transform(ev, y, m, n_slots=ns, plains=pl.get(("stc", i)))
         return Ct(y.data, y.level, natural)

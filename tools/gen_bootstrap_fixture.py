@@ -21,6 +21,17 @@ for log_n in (10, 11, 13, 16):
             entry[name] = {"diagonals": [sorted(int(k) for k in idx[i]) for i in range(depth)],
                            "rotations": sorted(int(r) for r in p.rotations())}
         out["logn%d_cts%d_stc%d" % (log_n, cts_depth, stc_depth)] = entry
+# sparse packing: the whole rotation list of a bootstrap (SubSum + both transforms), frontend/custom_task.py:469-486
+for log_n, log_slots in ((11, 8), (11, 9), (13, 9), (13, 11), (16, 11)):
+    rots = [1 << i for i in range(log_slots, log_n - 1)]
+    try:
+        for lt, depth in ((LinearTransformType.CoeffsToSlots, 4), (LinearTransformType.SlotsToCoeffs, 3)):
+            p = EncodingMatrixParams(linear_transform_type=lt, repack_imag_2_real=True, level_start=24, bit_reversed=False,
+                                     bsgs_ratio=2.0, scaling_factor=[[1.0]] * depth, log_n=log_n, log_slots=log_slots)
+            rots += p.rotations()
+    except ZeroDivisionError:      # the planner divides by the giant-step count, which is 0 for very small matrices
+        continue
+    out["sparse_logn%d_slots%d_cts4_stc3" % (log_n, log_slots)] = {"rotations": sorted(set(int(r) for r in rots))}
 path = os.path.join(ROOT, "tests", "golden", "bootstrap", "planner_rotations.json")
 json.dump(out, open(path, "w"))
 print(path, os.path.getsize(path))
