@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-fuse", action="store_true", help="separate ModDown/rescale tail kernels (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=4)
+    ap.add_argument("--log-slots", type=int, default=0, help="bootstrap workload: log2 of the packed slots (0 = dense, N/2)")
     return ap.parse_args()
 
 
@@ -209,7 +210,7 @@ def run_bootstrap_workload(args):
         return out
 
     t0 = time.perf_counter()
-    plan = BootstrapPlan(ctx, in_scale=2.0 ** 40, out_scale=2.0 ** 40)
+    plan = BootstrapPlan(ctx, in_scale=2.0 ** 40, out_scale=2.0 ** 40, log_slots=args.log_slots)
     t_plan = time.perf_counter() - t0
     keep = []
 
@@ -260,7 +261,8 @@ def run_bootstrap_workload(args):
         "metric": "ckks_bootstrap_throughput", "value": batch * args.steps / dt, "unit": "bootstraps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "CKKS bootstrap N=2^16 25Q+5P (N16QP1546H192H32), level 0 -> %d" % plan.out_level,
+        "config": {"workload": "CKKS bootstrap N=2^16 25Q+5P (N16QP1546H192H32), %s, level 0 -> %d" % (
+            "2^%d slots" % args.log_slots if plan.sparse else "dense packing", plan.out_level),
                    "batch_per_gpu": batch, "galois_keys": len(glk), "key_bytes_total": sum(t.numel() * 8 for t in keep),
                    "plan_build_s": t_plan, "ms_per_bootstrap": dt / args.steps / batch * 1e3},
         "roofline": roofline, "cpu_baseline": None, "kernel_breakdown": breakdown}), flush=True)

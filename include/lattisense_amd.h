@@ -135,12 +135,15 @@ int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib);
  * (cosine of range k with `double_angle` doublings, message ratio) and the list of Galois elements a run needs -- the
  * rotation set of the reference's planner (frontend/bootstrap_params.py:104-263) plus the conjugation.  in_scale: scale
  * of the level-0 input; out_scale: scale the refreshed ciphertext must have (0: whatever falls out).  The context's chain
- * must have cts_depth + 5 + double_angle + stc_depth levels above the output level.
+ * must have cts_depth + 5 + double_angle + stc_depth levels above the output level.  log_slots: 0 or log2(N)-1 for dense
+ * packing, smaller for sparsely packed ciphertexts (SubSum, one EvalMod on the packed real|imaginary halves, repacking
+ * SlotsToCoeffs).  lsa_bootstrap_info reports n_cts negated for a sparse plan; its matrices are then ordered
+ * [leading CoeffsToSlots ..., P1, P2, SlotsToCoeffs ...].
  * lsa_ckks_bootstrap: in [batch][2][1][N] -> out [batch][2][out_level+1][N]; swk_dts / swk_std (both or neither) are the
  * sparse-secret encapsulation keys at level 0 / top level (custom_task.py:1989-1996). */
 typedef struct lsa_bootstrap_st* lsa_bootstrap;
 int lsa_bootstrap_create(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
-                         double in_scale, double out_scale, void* stream, lsa_bootstrap* out);
+                         double in_scale, double out_scale, int log_slots, void* stream, lsa_bootstrap* out);
 void lsa_bootstrap_destroy(lsa_bootstrap b);
 int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* n_galois, int* n_matrices, int* n_cts);
 int lsa_bootstrap_galois_elements(lsa_bootstrap b, uint64_t* out, int capacity);

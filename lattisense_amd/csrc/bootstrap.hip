@@ -137,6 +137,25 @@ std::vector<Diags> merged_matrices(int n, int depth, bool inverse) {
     return mats;
 }
 
+// group sizes of `depth` merged matrices over log_n layers (frontend/bootstrap_params.py:104-119)
+std::vector<int> group_sizes(int log_n, int depth, bool inverse) {
+    std::vector<int> sizes;
+    int left = log_n;
+    for (int i = 0; i < depth; i++) {
+        const int s = (left + (depth - i) - 1) / (depth - i);
+        sizes.push_back(s);
+        left -= s;
+    }
+    if (!inverse) std::reverse(sizes.begin(), sizes.end());
+    return sizes;
+}
+
+std::vector<cplx> tiled(const std::vector<cplx>& v, int n) {
+    std::vector<cplx> out(n);
+    for (int t = 0; t < n; t++) out[t] = v[t % v.size()];
+    return out;
+}
+
 void bsgs_sets(const std::vector<int>& ks, int n, int n1, std::vector<int>& giants, std::vector<int>& babies) {
     std::map<int, bool> g, b;
     for (int k : ks) {
@@ -198,6 +217,7 @@ long long round_even(double v) { return (long long)std::nearbyint(v); }   // Pyt
 // ------------------------------------------------------------------------------------------------ plan
 struct BtMatrix {
     int level = 0, n1 = 1;
+    int period = 0;                      // period of the diagonals (index arithmetic mod period); N/2 for dense packing
     bool naive = false;
     std::vector<int> ks;                 // diagonal indices, ascending
     std::vector<u64*> plains;            // per diagonal: NTT-domain plaintext [level+1][N] of rot_{-giant}(diag)
@@ -207,7 +227,10 @@ struct Bootstrap {
     Context& c;
     int cts_depth, stc_depth, K, r, top_level;
     double mr, in_scale, out_scale;
+    int log_slots = 0;                   // 0 / logN-1: dense packing; less: sparse (subring of X^gap)
+    bool sparse = false;
     std::vector<BtMatrix> cts, stc;
+    BtMatrix p1, p2;                     // sparse: last CoeffsToSlots matrix split for x and conj(x), real | imaginary halves
     std::vector<double> cheb;            // 32 Chebyshev coefficients of cos(2 pi (K x - 1/4) / 2^r) on [-1,1]
     u64* mono[2] = {nullptr, nullptr};   // NTT of +X^(N/2) and -X^(N/2), [top_level+1][N]
     std::vector<u64> galois;             // Galois elements a run needs (rotations + conjugation)
@@ -279,10 +302,76 @@ struct Bootstrap {
         const int evalmod_level = top_level - cts_depth;
         const int stc_level = evalmod_level - 5 - r;
         natural_scale = evalmod_out_scale(evalmod_level) * 2.0 * kPi * d1 / q0;
-        std::vector<Diags> mc = merged_matrices(n, cts_depth, true), ms = merged_matrices(n, stc_depth, false);
-        const double g = 1.0 / (2.0 * (double)n * (double)K);   // 1/n (inverse FFT), 1/2 (t + conj t), 1/K (unit interval)
-        for (auto& kv : mc[0])
-            for (auto& v : kv.second) v *= g;
+        int logn_ring = 0;
+        while ((1 << logn_ring) < c.n) logn_ring++;
+        sparse = log_slots > 0 && log_slots < logn_ring - 1;
+        const int ns = sparse ? 1 << log_slots : n;
+        std::vector<Diags> mc = merged_matrices(ns, cts_depth, true), ms;
+        Diags dp1, dp2;
+        if (!sparse) {
+            ms = merged_matrices(n, stc_depth, false);
+            const double g = 1.0 / (2.0 * (double)n * (double)K);   // 1/n (inverse FFT), 1/2 (t + conj t), 1/K (unit interval)
+            for (auto& kv : mc[0])
+                for (auto& v : kv.second) v *= g;
+        } else {
+            // see oracle/ckks_bootstrap.py SparseBootstrapper: last CtS matrix M as y = P1 x + P2 conj(x) on period 2*ns
+            // (first half Re(Mx), second half Im(Mx)); StC's first matrix preceded by the repack R = {0, ns}
+            const int gap = n / ns;
+            Diags last = mc.back();
+            mc.pop_back();
+            for (auto& kv : last) {
+                std::vector<cplx> a(2 * ns), b(2 * ns);
+                for (int t = 0; t < ns; t++) {
+                    const cplx d = kv.second[t];
+                    a[t] = 0.5 * d;
+                    a[t + ns] = cplx(0.0, -0.5) * d;
+                    b[t] = 0.5 * std::conj(d);
+                    b[t + ns] = cplx(0.0, 0.5) * std::conj(d);
+                }
+                dp1[kv.first] = a;
+                dp2[kv.first] = b;
+            }
+            const double g = 1.0 / ((double)ns * (double)gap * (double)K);   // 1/slots, 1/gap (SubSum), 1/K
+            if (!mc.empty()) {
+                for (auto& kv : mc[0])
+                    for (auto& v : kv.second) v *= g;
+            } else {
+                for (auto* dd : {&dp1, &dp2})
+                    for (auto& kv : *dd)
+                        for (auto& v : kv.second) v *= g;
+            }
+            const std::vector<int> rgs = rot_group(ns);
+            const std::vector<int> sizes = group_sizes(log_slots, stc_depth, false);
+            Diags m;
+            {
+                std::vector<cplx> e(2 * ns), f(2 * ns);
+                for (int t = 0; t < ns; t++) {
+                    e[t] = 1.0;
+                    e[t + ns] = cplx(0.0, 1.0);
+                    f[t] = cplx(0.0, 1.0);
+                    f[t + ns] = 1.0;
+                }
+                m[0] = e;
+                m[ns] = f;
+            }
+            int pos = 0;
+            for (size_t gi = 0; gi < sizes.size(); gi++) {
+                bool have = gi == 0;
+                for (int i = 0; i < sizes[gi]; i++) {
+                    Diags lay = layer_diagonals(ns, 1 << (pos + i + 1), false, rgs);
+                    if (gi == 0) {
+                        for (auto& kv : lay) kv.second = tiled(kv.second, 2 * ns);
+                        m = compose(m, lay, 2 * ns);
+                    } else {
+                        m = have ? compose(m, lay, ns) : lay;
+                        have = true;
+                    }
+                }
+                ms.push_back(m);
+                m.clear();
+                pos += sizes[gi];
+            }
+        }
         if (out_scale > 0) {
             const double kappa = out_scale / natural_scale;
             for (auto& kv : ms[0])
@@ -296,29 +385,34 @@ struct Bootstrap {
             for (int i = 0; i < rot % n; i++) e = e * 5 % m;
             return e;
         };
-        auto make = [&](std::vector<Diags>& mats, int level0, std::vector<BtMatrix>& out) {
-            for (size_t i = 0; i < mats.size(); i++) {
-                BtMatrix bm;
-                bm.level = level0 - (int)i;
-                for (auto& kv : mats[i]) bm.ks.push_back(kv.first);
-                bm.naive = bm.ks.size() < 3;
-                bm.n1 = bm.naive ? 1 : bsgs_split(bm.ks, n, 2.0);
-                const double pt_scale = (double)c.T.mod[bm.level];
-                for (int k : bm.ks) {
-                    const int giant = bm.naive ? 0 : (k / bm.n1) * bm.n1;
-                    const std::vector<cplx>& d = mats[i][k];
-                    std::vector<cplx> rolled(n);
-                    for (int t = 0; t < n; t++) rolled[t] = d[((t - giant) % n + n) % n];   // rot_{-giant}(diag)
-                    bm.plains.push_back(upload_plain(slots_to_coeffs(rolled, rg), pt_scale, bm.level, s));
-                    const int baby = bm.naive ? k : k - giant;
-                    if (baby) gal[gel(baby)] = true;
-                    if (giant) gal[gel(giant)] = true;
-                }
-                out.push_back(std::move(bm));
+        // one matrix -> plaintexts (diagonals of period `period`, tiled over the N/2 slots) + the rotations it needs
+        auto make_one = [&](const Diags& mat, int level, int period) {
+            BtMatrix bm;
+            bm.level = level;
+            bm.period = period;
+            for (auto& kv : mat) bm.ks.push_back(kv.first);
+            bm.naive = bm.ks.size() < 3;
+            bm.n1 = bm.naive ? 1 : bsgs_split(bm.ks, period, 2.0);
+            const double pt_scale = (double)c.T.mod[bm.level];
+            for (int k : bm.ks) {
+                const int giant = bm.naive ? 0 : (k / bm.n1) * bm.n1;
+                const std::vector<cplx>& d = mat.at(k);
+                std::vector<cplx> rolled(n);
+                for (int t = 0; t < n; t++) rolled[t] = d[(((t - giant) % period) + period) % period];   // rot_{-giant}(diag), tiled
+                bm.plains.push_back(upload_plain(slots_to_coeffs(rolled, rg), pt_scale, bm.level, s));
+                const int baby = bm.naive ? k : k - giant;
+                if (baby) gal[gel(baby)] = true;
+                if (giant) gal[gel(giant)] = true;
             }
+            return bm;
         };
-        make(mc, top_level, cts);
-        make(ms, stc_level, stc);
+        for (size_t i = 0; i < mc.size(); i++) cts.push_back(make_one(mc[i], top_level - (int)i, ns));
+        if (sparse) {
+            p1 = make_one(dp1, top_level - (int)mc.size(), 2 * ns);
+            p2 = make_one(dp2, top_level - (int)mc.size(), 2 * ns);
+            for (int i = log_slots; i < logn_ring - 1; i++) gal[gel(1 << i)] = true;   // SubSum
+        }
+        for (size_t i = 0; i < ms.size(); i++) stc.push_back(make_one(ms[i], stc_level - (int)i, sparse && i == 0 ? 2 * ns : ns));
         gal[2ULL * c.n - 1] = true;
         for (auto& kv : gal) galois.push_back(kv.first);
         // Chebyshev interpolant (first-kind nodes) of cos(2 pi (K x - 1/4) / 2^r), 32 coefficients
@@ -520,7 +614,7 @@ struct Eval {
         return o;
     }
 
-    DCt linear_transform(const DCt& ct, const BtMatrix& mt) {
+    DCt linear_transform(const DCt& ct, const BtMatrix& mt, bool do_rescale = true) {
         LSA_REQUIRE(ct.level == mt.level, "bootstrap: linear transform applied at an unexpected level");
         const double pt_scale = q(ct.level);
         const int L = ct.level + 1;
@@ -554,7 +648,7 @@ struct Eval {
             std::vector<std::pair<const u64*, const DCt*>> terms;
             for (size_t i = 0; i < mt.ks.size(); i++) terms.push_back({mt.plains[i], &baby(mt.ks[i])});
             acc = mac(terms);
-            return rescale(acc);
+            return do_rescale ? rescale(acc) : acc;
         }
         std::map<int, std::vector<size_t>> by_giant;
         for (size_t i = 0; i < mt.ks.size(); i++) by_giant[(mt.ks[i] / mt.n1) * mt.n1].push_back(i);
@@ -565,7 +659,7 @@ struct Eval {
             acc = have ? add(acc, inner) : inner;
             have = true;
         }
-        return rescale(acc);
+        return do_rescale ? rescale(acc) : acc;
     }
 
     DCt eval_chebyshev(const DCt& u, const std::vector<double>& coeffs) {
@@ -627,8 +721,9 @@ struct Eval {
 }  // namespace
 
 Bootstrap* bootstrap_create(Context& c, int cts_depth, int stc_depth, int K, int double_angle, double message_ratio,
-                            double in_scale, double out_scale, hipStream_t s) {
+                            double in_scale, double out_scale, int log_slots, hipStream_t s) {
     auto b = std::make_unique<Bootstrap>(c);
+    b->log_slots = log_slots;
     b->cts_depth = cts_depth;
     b->stc_depth = stc_depth;
     b->K = K;
@@ -683,20 +778,35 @@ void bootstrap_run(Bootstrap& bt, const u64* in, long long sin, u64* out, long l
         ckks_switch_key(c, bt.top_level, x.data(), *swk_std, y.data(), batch, ev.stride(bt.top_level), ev.stride(bt.top_level), s);
         x = y;
     }
+    if (bt.sparse) {   // SubSum: trace onto the subring of the sparse packing
+        int logn_ring = 0;
+        while ((1 << logn_ring) < c.n) logn_ring++;
+        for (int i = bt.log_slots; i < logn_ring - 1; i++) x = ev.add(x, ev.rotate(x, 1 << i));
+    }
     for (auto& mt : bt.cts) {
         x = ev.linear_transform(x, mt);
         LSA_BT_CHECK(x)   // 3 .. 2+cts_depth
     }
-    DCt xc = ev.conj(x);
-    DCt u_re = ev.add(x, xc);
-    LSA_BT_CHECK(u_re)
-    DCt u_im = ev.mul_by_i(ev.sub(x, xc), -1);
-    LSA_BT_CHECK(u_im)
-    DCt y_re = ev.eval_mod(u_re);
-    LSA_BT_CHECK(y_re)
-    DCt y_im = ev.eval_mod(u_im);
-    DCt y = ev.add(y_re, ev.mul_by_i(y_im, 1));
-    LSA_BT_CHECK(y)
+    DCt y;
+    if (bt.sparse) {
+        DCt a = ev.linear_transform(x, bt.p1, false);
+        DCt b = ev.linear_transform(ev.conj(x), bt.p2, false);
+        DCt u = ev.rescale(ev.add(a, b));          // [Re(t)/K | Im(t)/K], period 2*slots
+        LSA_BT_CHECK(u)
+        y = ev.eval_mod(u);
+        LSA_BT_CHECK(y)
+    } else {
+        DCt xc = ev.conj(x);
+        DCt u_re = ev.add(x, xc);
+        LSA_BT_CHECK(u_re)
+        DCt u_im = ev.mul_by_i(ev.sub(x, xc), -1);
+        LSA_BT_CHECK(u_im)
+        DCt y_re = ev.eval_mod(u_re);
+        LSA_BT_CHECK(y_re)
+        DCt y_im = ev.eval_mod(u_im);
+        y = ev.add(y_re, ev.mul_by_i(y_im, 1));
+        LSA_BT_CHECK(y)
+    }
     for (auto& mt : bt.stc) y = ev.linear_transform(y, mt);
 #undef LSA_BT_CHECK
     std::vector<int> all(2 * (y.level + 1));
@@ -710,11 +820,14 @@ int bootstrap_out_level(const Bootstrap& bt) { return bt.top_level - bt.cts_dept
 double bootstrap_out_scale(const Bootstrap& bt) { return bt.natural_scale; }
 const std::vector<u64>& bootstrap_galois(const Bootstrap& bt) { return bt.galois; }
 const std::vector<double>& bootstrap_chebyshev(const Bootstrap& bt) { return bt.cheb; }
-int bootstrap_matrices(const Bootstrap& bt) { return (int)(bt.cts.size() + bt.stc.size()); }
+// matrix order: the leading CoeffsToSlots matrices, (sparse packing: P1, P2,) the SlotsToCoeffs matrices
+int bootstrap_matrices(const Bootstrap& bt) { return (int)(bt.cts.size() + bt.stc.size()) + (bt.sparse ? 2 : 0); }
 int bootstrap_cts_matrices(const Bootstrap& bt) { return (int)bt.cts.size(); }
+bool bootstrap_is_sparse(const Bootstrap& bt) { return bt.sparse; }
 void bootstrap_matrix(const Bootstrap& bt, int i, int* level, int* n1, const std::vector<int>** ks, const std::vector<u64*>** plains) {
     LSA_REQUIRE(i >= 0 && i < bootstrap_matrices(bt), "bootstrap: matrix index out of range");
-    const BtMatrix& m = i < (int)bt.cts.size() ? bt.cts[i] : bt.stc[i - bt.cts.size()];
+    const int nc = (int)bt.cts.size(), extra = bt.sparse ? 2 : 0;
+    const BtMatrix& m = i < nc ? bt.cts[i] : (i < nc + extra ? (i == nc ? bt.p1 : bt.p2) : bt.stc[i - nc - extra]);
     *level = m.level;
     *n1 = m.naive ? 0 : m.n1;
     *ks = &m.ks;

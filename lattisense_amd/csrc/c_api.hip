@@ -348,13 +348,14 @@ struct lsa_bootstrap_st {
     Context* c;
 };
 int lsa_bootstrap_create(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
-                         double in_scale, double out_scale, void* stream, lsa_bootstrap* out) {
+                         double in_scale, double out_scale, int log_slots, void* stream, lsa_bootstrap* out) {
     return guard([&] {
         LSA_REQUIRE(out != nullptr, "null argument");
         LSA_REQUIRE(k >= 1 && double_angle >= 0 && double_angle <= 8 && message_ratio > 0 && in_scale > 0, "bad bootstrap parameters");
         auto h = std::make_unique<lsa_bootstrap_st>();
         h->c = &C(ctx);
-        h->b = bootstrap_create(C(ctx), cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale, S(stream));
+        LSA_REQUIRE(log_slots >= 0 && (log_slots == 0 || (2 << log_slots) <= C(ctx).n), "bad slot count");
+        h->b = bootstrap_create(C(ctx), cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale, log_slots, S(stream));
         *out = h.release();
     });
 }
@@ -370,7 +371,7 @@ int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* 
         if (out_scale) *out_scale = bootstrap_out_scale(*b->b);
         if (n_galois) *n_galois = (int)bootstrap_galois(*b->b).size();
         if (n_matrices) *n_matrices = bootstrap_matrices(*b->b);
-        if (n_cts) *n_cts = bootstrap_cts_matrices(*b->b);
+        if (n_cts) *n_cts = bootstrap_cts_matrices(*b->b) * (bootstrap_is_sparse(*b->b) ? -1 : 1);   // negative: sparse packing
     });
 }
 int lsa_bootstrap_galois_elements(lsa_bootstrap b, uint64_t* out, int capacity) {

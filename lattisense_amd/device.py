@@ -204,16 +204,17 @@ class BootstrapPlan:
     """Device-side CKKS bootstrapping plan (include/lattisense_amd.h: lsa_bootstrap_*)."""
 
     def __init__(self, ctx, cts_depth=4, stc_depth=3, k=16, double_angle=3, message_ratio=256.0, in_scale=2.0 ** 40,
-                 out_scale=0.0):
+                 out_scale=0.0, log_slots=0):
         self.ctx = ctx
         h = ctypes.c_void_p()
         check(lib().lsa_bootstrap_create(ctx.h, cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale,
-                                         ctx.stream, ctypes.byref(h)))
+                                         log_slots, ctx.stream, ctypes.byref(h)))
         self.h = h
         lv, sc, ng, nm, nc = ctypes.c_int(), ctypes.c_double(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(lib().lsa_bootstrap_info(self.h, ctypes.byref(lv), ctypes.byref(sc), ctypes.byref(ng), ctypes.byref(nm),
                                        ctypes.byref(nc)))
-        self.out_level, self.out_scale, self.n_matrices, self.n_cts = lv.value, sc.value, nm.value, nc.value
+        self.out_level, self.out_scale, self.n_matrices = lv.value, sc.value, nm.value
+        self.sparse, self.n_cts = nc.value < 0, abs(nc.value)
         g = (ctypes.c_uint64 * ng.value)()
         check(lib().lsa_bootstrap_galois_elements(self.h, g, ng.value))
         self.galois_elements = [int(x) for x in g]
@@ -250,3 +251,9 @@ class BootstrapPlan:
         check(lib().lsa_ckks_bootstrap(self.ctx.h, self.h, in_buf.ptr, out.ptr, batch, 2 * n, 2 * (self.out_level + 1) * n, rlk,
                                        len(glk), elts, keys, swk_dts, swk_std, self.ctx.stream))
         return out
+
+    def oracle_plains(self):
+        """the plan's encoded diagonals keyed as oracle/ckks_bootstrap.py expects them"""
+        keys = [("cts", i) for i in range(self.n_cts)] + ([("p1",), ("p2",)] if self.sparse else [])
+        keys += [("stc", i) for i in range(self.n_matrices - len(keys))]
+        return {k: self.matrix(i)[3] for i, k in enumerate(keys)}

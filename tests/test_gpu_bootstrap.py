@@ -25,11 +25,7 @@ def _setup(log_n, hamming, seed):
 
 
 def _oracle_plains(plan):
-    plains = {}
-    for i in range(plan.n_matrices):
-        _, _, _, pts = plan.matrix(i)
-        plains[("cts", i) if i < plan.n_cts else ("stc", i - plan.n_cts)] = pts
-    return plains
+    return plan.oracle_plains()
 
 
 @pytest.mark.parametrize("log_n,encapsulate", [(10, False), (11, True)])
@@ -112,9 +108,7 @@ def test_bootstrap_node_through_the_task_boundary():
     ctx = DeviceContext(ALGO_CKKS, n, q, p)
     plan = BootstrapPlan(ctx, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
                          P["btp_eval_mod_message_ratio"], D, D)
-    plains = {}
-    for i in range(plan.n_matrices):
-        plains[("cts", i) if i < plan.n_cts else ("stc", i - plan.n_cts)] = plan.matrix(i)[3]
+    plains = plan.oracle_plains()
     bt = Bootstrapper(ev, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
                       P["btp_eval_mod_message_ratio"], out_scale=D, plains=plains, coeffs=plan.chebyshev())
     for i in range(2):
@@ -123,3 +117,36 @@ def test_bootstrap_node_through_the_task_boundary():
         assert np.array_equal(ys[i].data, bt.bootstrap(Ct(cts[i], 0, D), top, dts, std).data)
     plan.close()
     t.close()
+
+
+def test_sparse_slot_bootstrap_bit_exact_against_the_oracle_program():
+    """Sparsely packed ciphertexts (2^9 of 2^10 slots at N = 2^11; the reference's sparse bootstrap parameter set is
+    log_slots = 11 at N = 2^16, unittests/fixture.hpp:152-162)."""
+    need_gpu()
+    from lattisense_amd.device import BootstrapPlan
+    from oracle.ckks_bootstrap import Ct, Evaluator, SparseBootstrapper
+    from oracle.client import mean_precision_bits
+    log_n, log_slots = 11, 9
+    B, N, o, c, ctx = _setup(log_n, 32, 77)
+    ns = 1 << log_slots
+    top = len(B["q"]) - 1
+    D = float(2 ** 40)
+    plan = BootstrapPlan(ctx, in_scale=D, out_scale=D, log_slots=log_slots)
+    assert plan.sparse and plan.out_level == 9 and plan.out_scale == D
+    ev = Evaluator(o, c, top)
+    keys = {e: c.gen_galois_key(e, top) for e in plan.galois_elements}
+    ev.glk = dict(keys)
+    rlk = ctx.upload_key(ev.rlk, top)
+    glk = {e: ctx.upload_key(k, top) for e, k in keys.items()}
+    rng = np.random.default_rng(78)
+    z = rng.uniform(-1, 1, ns) + 1j * rng.uniform(-1, 1, ns)
+    ct = c.ckks_encrypt(np.tile(z, (N // 2) // ns), 0, D)
+    out = plan.run(ctx.upload(ct[None]), 1, rlk, glk)
+    got = ctx.download(out, (1, 2, plan.out_level + 1, N))[0]
+    want = SparseBootstrapper(ev, log_slots, out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev()).bootstrap(
+        Ct(ct, 0, D), top)
+    assert np.array_equal(got, want.data)
+    re, im = mean_precision_bits(z, c.ckks_decrypt(got, D)[:ns])
+    assert re >= 10 and im >= 10
+    assert sorted(ev.glk) == sorted(plan.galois_elements)
+    plan.close()
