@@ -801,9 +801,19 @@ void bootstrap_run(Bootstrap& bt, const u64* in, long long sin, u64* out, long l
         LSA_BT_CHECK(u_re)
         DCt u_im = ev.mul_by_i(ev.sub(x, xc), -1);
         LSA_BT_CHECK(u_im)
-        DCt y_re = ev.eval_mod(u_re);
+        // both halves go through EvalMod as ONE batch of 2m ciphertexts (ciphertexts of a batch are independent: same
+        // residues as two separate evaluations, half the launches -- what a single-ciphertext bootstrap is bound by)
+        Eval ev2(c, bt, s, 2 * batch, rlk, glk);
+        DCt uu = ev2.alloc(u_re.level, u_re.scale);
+        const size_t half_bytes = (size_t)batch * ev.stride(u_re.level) * sizeof(u64);
+        LSA_HIP(hipMemcpyAsync(uu.data(), u_re.data(), half_bytes, hipMemcpyDeviceToDevice, s));
+        LSA_HIP(hipMemcpyAsync(uu.data() + (size_t)batch * ev.stride(u_re.level), u_im.data(), half_bytes, hipMemcpyDeviceToDevice, s));
+        DCt yy = ev2.eval_mod(uu);
+        DCt y_re = ev.alloc(yy.level, yy.scale), y_im = ev.alloc(yy.level, yy.scale);
+        const size_t out_bytes = (size_t)batch * ev.stride(yy.level) * sizeof(u64);
+        LSA_HIP(hipMemcpyAsync(y_re.data(), yy.data(), out_bytes, hipMemcpyDeviceToDevice, s));
+        LSA_HIP(hipMemcpyAsync(y_im.data(), yy.data() + (size_t)batch * ev.stride(yy.level), out_bytes, hipMemcpyDeviceToDevice, s));
         LSA_BT_CHECK(y_re)
-        DCt y_im = ev.eval_mod(u_im);
         y = ev.add(y_re, ev.mul_by_i(y_im, 1));
         LSA_BT_CHECK(y)
     }
