@@ -31,6 +31,8 @@ namespace lsa {
 void ckks_relin(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
 void ckks_rescale(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
 void ckks_rotate(Context&, int, const u64*, u64, const Key&, u64*, int, long long, long long, hipStream_t);
+void ckks_rotate_many(Context&, int, const u64*, int, const u64*, const Key* const*, u64* const*, int, long long, long long,
+                      hipStream_t);
 void ckks_mult_relin_rescale(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long, long long,
                              hipStream_t);
 void bfv_mult(Context&, int, const u64*, const u64*, u64*, int, long long, long long, long long, hipStream_t);
@@ -923,6 +925,81 @@ struct fhe_task_handle_st {
         pending_free().push_back(out_slab);  // (cheap: shared) keeps frees off the critical path until the level ends
     }
 
+    // Buckets of one level.  CKKS rotations of the SAME ciphertexts by different Galois elements (the frontend's rotate_cols
+    // emits them for convolutions: examples/benchmark_convolution) are hoisted: one decomposition of the inputs, then only
+    // the key MAC + ModDown + permutation per element (ckks_rotate_many; same residues as separate rotations).
+    void run_buckets(Context& c, hipStream_t s, std::map<std::string, std::vector<ComputeNode*>>& buckets,
+                     const std::vector<std::string>& order, std::unordered_map<NodeIndex, std::any>& avail) {
+        std::map<std::vector<NodeIndex>, std::vector<const std::string*>> rot_groups;
+        if (g.algo == ALGO_CKKS)
+            for (auto& sg : order) {
+                auto& nodes = buckets[sg];
+                const OperationType op = nodes[0]->op();
+                if (op != OperationType::ROTATE_COL && op != OperationType::ROTATE_ROW) continue;
+                std::vector<NodeIndex> ins;
+                for (auto* n : nodes) ins.push_back(n->input_nodes[0]->index);
+                rot_groups[ins].push_back(&sg);
+            }
+        std::unordered_set<const std::string*> done;
+        for (auto& sg : order) {
+            if (done.count(&sg)) continue;
+            auto& nodes = buckets[sg];
+            const OperationType op = nodes[0]->op();
+            std::vector<const std::string*>* group = nullptr;
+            if (g.algo == ALGO_CKKS && (op == OperationType::ROTATE_COL || op == OperationType::ROTATE_ROW)) {
+                std::vector<NodeIndex> ins;
+                for (auto* n : nodes) ins.push_back(n->input_nodes[0]->index);
+                auto& gr = rot_groups[ins];
+                if (gr.size() >= 2) group = &gr;
+            }
+            if (!group) {
+                run_gpu_bucket(c, s, nodes, avail);
+                last_gpu_nodes += (int)nodes.size();
+                last_gpu_batches++;
+                continue;
+            }
+            // hoisted group: same inputs, one Galois element per member bucket
+            const long long N = c.n;
+            const ComputeNode* n0 = nodes[0];
+            const int lvl = n0->input_nodes[0]->fhe_prop->level, L = lvl + 1, m = (int)nodes.size();
+            LSA_REQUIRE(n0->input_nodes[0]->fhe_prop->degree == 1, "rotation expects a degree-1 ciphertext");
+            const size_t w = (size_t)2 * L * N;
+            Operand a = gather(c, s, nodes, 0, avail, w);
+            std::vector<u64> els;
+            std::vector<const Key*> keys;
+            std::vector<u64*> outs;
+            std::vector<std::shared_ptr<Slab>> slabs;
+            for (const std::string* member : *group) {
+                auto& mn = buckets[*member];
+                const ComputeNode* r0 = mn[0];
+                const DatumNode* kd = r0->input_nodes[1];
+                const u64 gel = r0->op() == OperationType::ROTATE_ROW ? 2 * (u64)c.n - 1
+                                                                      : (kd->fhe_prop->p ? kd->fhe_prop->p->galois_element : 0);
+                LSA_REQUIRE(gel != 0, "Galois element missing on the key datum");
+                els.push_back(gel);
+                keys.push_back(&std::any_cast<KeyP>(avail.at(kd->index))->key);
+                slabs.push_back(dslab(w * m));
+                outs.push_back(slabs.back()->ptr);
+            }
+            ckks_rotate_many(c, lvl, a.ptr, (int)els.size(), els.data(), keys.data(), outs.data(), m, a.stride, (long long)w, s);
+            for (size_t gi = 0; gi < group->size(); gi++) {
+                auto& mn = buckets[*(*group)[gi]];
+                for (int i = 0; i < m; i++) {
+                    auto d = std::make_shared<DevDatum>();
+                    d->slab = slabs[gi];
+                    d->ptr = outs[gi] + w * i;
+                    d->polys = 2;
+                    d->level = lvl;
+                    avail[mn[i]->output_nodes[0]->index] = d;
+                }
+                pending_free().push_back(slabs[gi]);
+                last_gpu_nodes += m;
+                done.insert((*group)[gi]);
+            }
+            last_gpu_batches++;
+        }
+    }
+
     // ---------------------------------------------------------------- CPU-side nodes (export / import / custom)
     void run_cpu_nodes(const std::vector<ComputeNode*>& nodes, std::unordered_map<NodeIndex, std::any>& avail,
                        const std::unordered_map<NodeIndex, void*>& out_handles) {
@@ -1060,11 +1137,7 @@ struct fhe_task_handle_st {
             }
             const double t_load = ms_since(t0);
             t0 = tick();
-            for (auto& sg : sp.bucket_order) {
-                run_gpu_bucket(c, s, sp.buckets[sg], avail);
-                last_gpu_nodes += (int)sp.buckets[sg].size();
-                last_gpu_batches++;
-            }
+            run_buckets(c, s, sp.buckets, sp.bucket_order, avail);
             if (trace && !sp.bucket_order.empty()) LSA_HIP(hipStreamSynchronize(s));
             const double t_gpu = ms_since(t0);
             t0 = tick();
@@ -1149,11 +1222,7 @@ struct fhe_task_handle_st {
                     }
                     if (!sp.cpu.empty()) run_cpu_nodes(sp.cpu, avail, out_handles);   // export executors
                     if (!sp.loads.empty()) f.keep.push_back(run_loads(lc, ls, sp.loads, avail));
-                    for (auto& sg : sp.bucket_order) {
-                        run_gpu_bucket(lc, ls, sp.buckets[sg], avail);
-                        last_gpu_nodes += (int)sp.buckets[sg].size();
-                        last_gpu_batches++;
-                    }
+                    run_buckets(lc, ls, sp.buckets, sp.bucket_order, avail);
                     release_inputs(cl[l]);
                     progress(cl[l].size());
                 }
