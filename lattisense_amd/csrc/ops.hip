@@ -42,11 +42,13 @@ struct KsRescale {
 // With `rs` (needs fused tails): p is scratch of the same shape and rs->out receives rescale(p).
 static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
-                      const KsRescale* rs);
+                      const KsRescale* rs, bool coeff_out = false);
 
 // steps 1-3: cx out of the NTT domain, every digit converted to the other limbs of Q u P, extended limbs back into the
-// NTT domain (workspace layout: cxi | ext | acc | conv)
-static void ks_decompose(Context& c, int level, const u64* cx, long long scx, int nb, u64* ws, hipStream_t s) {
+// NTT domain (workspace layout: cxi | ext | acc | conv).  cx_coef: the same polynomial in the coefficient domain if the
+// caller has it (BFV): the inverse transform is skipped.
+static void ks_decompose(Context& c, int level, const u64* cx, long long scx, int nb, u64* ws, hipStream_t s,
+                         const u64* cx_coef = nullptr, long long s_coef = 0) {
     LSA_REQUIRE(c.np >= 1, "key switching needs at least one special prime");
     LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
     const long long N = c.n;
@@ -56,7 +58,14 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
     const long long s_cxi = (long long)L * N, s_ext = (long long)beta * T * N;
 
     // 1. cx out of the NTT domain
-    launch_ntt(c, cx, cxi, nb, scx, s_cxi, L, rm_seq(L), true, s);
+    const u64* conv_src = cxi;
+    long long s_src = s_cxi;
+    if (cx_coef) {
+        conv_src = cx_coef;
+        s_src = s_coef;
+    } else {
+        launch_ntt(c, cx, cxi, nb, scx, s_cxi, L, rm_seq(L), true, s);
+    }
     // 2. per digit: exact conversion of the digit's limbs to every other limb of Q u P
     auto tl_mod = [&](int tl) { return tl < L ? tl : c.p_mod(tl - L); };
     for (int d = 0; d < beta; d++) {
@@ -72,7 +81,7 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
             rows.dst_row[dst.size()] = d * T + tl;
             dst.push_back(tl_mod(tl));
         }
-        launch_baseconv(c, c.baseconv(src, dst, false), rows, cxi, ext, nb, s_cxi, s_ext, s);
+        launch_baseconv(c, c.baseconv(src, dst, false), rows, conv_src, ext, nb, s_src, s_ext, s);
     }
     // 3. extended limbs into the NTT domain (the digit's own limbs are taken from cx directly by the MAC)
     if (beta * T <= LSA_MAX_PERIOD) {
@@ -102,7 +111,7 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
 // after the switch, as here, every rotation's residues are the same as if it had been computed on its own)
 static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
-                      const KsRescale* rs) {
+                      const KsRescale* rs, bool coeff_out) {
     const long long N = c.n;
     const int L = level + 1, np = c.np, T = L + np, beta = ceil_div(L, np);
     u64* cxi = ws;
@@ -112,14 +121,18 @@ static void ks_finish(Context& c, int level, const u64* cx, long long scx, const
     const long long s_ext = (long long)beta * T * N, s_acc = 2LL * T * N, s_conv = 2LL * L * N;
     // 4. gadget inner product with the key (both halves)
     launch_ks_mac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s);
-    // 5. ModDown: P-part out of NTT, centred exact conversion P -> Q, back to NTT, (accQ - conv) * P^-1 (+ base)
+    // 5. ModDown: P-part out of NTT, centred exact conversion P -> Q, back to NTT, (accQ - conv) * P^-1 (+ base).
+    //    coeff_out (BFV: the result is wanted in the coefficient domain and `base` is given there): every row of acc leaves
+    //    the NTT domain once and the tail runs on coefficients -- INTT((acc - NTT(conv)) * P^-1) == (INTT(acc) - conv) * P^-1
+    //    residue for residue, 2(L+k) transforms instead of 2k + 2L + 2L.
     {
         RowMap rm;
         rm.period = 2 * T;
         for (int h = 0; h < 2; h++)
             for (int tl = 0; tl < T; tl++)
                 rm.mod_of[h * T + tl] = tl >= L ? (unsigned char)c.p_mod(tl - L)
-                                                : (rs && tl == level ? (unsigned char)level : LSA_ROW_SKIP);
+                                                : (coeff_out ? (unsigned char)tl
+                                                             : (rs && tl == level ? (unsigned char)level : LSA_ROW_SKIP));
         launch_ntt(c, acc, acc, nb, s_acc, 2 * T, rm, true, s);
     }
     {
@@ -136,6 +149,10 @@ static void ks_finish(Context& c, int level, const u64* cx, long long scx, const
         const BaseConvPlan* k = c.baseconv(src, dst, true, rs != nullptr);
         for (int h = 0; h < 2; h++)
             launch_baseconv(c, k, rows, acc + (size_t)h * T * N, conv + (size_t)h * L * N, nb, s_acc, s_conv, s);
+    }
+    if (coeff_out) {
+        launch_moddown_final(c, level, acc, s_acc, T, conv, s_conv, base, sbase, base_rpp, base_polys, p, sp, nb, s);
+        return;
     }
     if (rs) {
         LSA_REQUIRE(c.fuse_tails && level >= 1 && base && base_polys == 2, "merged ModDown+rescale: unsupported shape");
@@ -482,15 +499,18 @@ void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int ba
 }
 
 // key switch of a coefficient-domain polynomial: NTT in, INTT out
+// cx in the coefficient domain; p[h] = (h < base_polys ? base[h] : 0) + KeySwitch(cx)[h], all in the coefficient domain.
+// Only the MAC's own-digit operand needs cx in the NTT domain; the decomposition starts from the coefficients the caller
+// already has and the ModDown tail runs on coefficients (ks_finish, coeff_out).
 static void bfv_key_switch(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
-                           int nb, u64* ws, hipStream_t s) {
+                           const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s) {
     const long long N = c.n;
     const int L = level + 1;
     u64* cxn = ws;
     u64* sub = ws + (size_t)nb * L * N;
     launch_ntt(c, cx, cxn, nb, scx, (long long)L * N, L, rm_seq(L), false, s);
-    key_switch(c, level, cxn, (long long)L * N, key, p, sp, nullptr, 0, 0, 0, nb, sub, s);
-    launch_ntt(c, p, p, nb, sp, 2 * L, rm_seq(L), true, s);
+    ks_decompose(c, level, cxn, (long long)L * N, nb, sub, s, cx, scx);
+    ks_finish(c, level, cxn, (long long)L * N, key, p, sp, base, sbase, base_rpp, base_polys, nb, sub, s, nullptr, true);
 }
 
 void bfv_relin(Context& c, int level, const u64* d3, const Key& rlk, u64* out, int batch, long long sd, long long so,
@@ -498,12 +518,9 @@ void bfv_relin(Context& c, int level, const u64* d3, const Key& rlk, u64* out, i
     const long long N = c.n;
     const int L = level + 1;
     const size_t ks_rows = ks_ws_rows(c, level) + L;
-    const long long sp = 2LL * L * N;
-    for_tiles(c, ks_rows + 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
-        u64* p = ws + ks_rows * N * tb;
+    for_tiles(c, ks_rows, batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
         const u64* d = d3 + (size_t)b0 * sd;
-        bfv_key_switch(c, level, d + 2LL * L * N, sd, rlk, p, sp, nb, ws, st);
-        launch_elementwise(c, EW_ADD, d, p, out + (size_t)b0 * so, nb, sd, sp, so, 2 * L, rm_seq(L), st);
+        bfv_key_switch(c, level, d + 2LL * L * N, sd, rlk, out + (size_t)b0 * so, so, d, sd, L, 2, nb, ws, st);
     });
 }
 
@@ -517,8 +534,7 @@ void bfv_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u64
     for_tiles(c, ks_rows + 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
         u64* p = ws + ks_rows * N * tb;
         const u64* ct = in + (size_t)b0 * sin;
-        bfv_key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, nb, ws, st);
-        launch_elementwise(c, EW_ADD, p, ct, p, nb, sp, sin, sp, L, rm_seq(L), st);  // p0 += c0
+        bfv_key_switch(c, level, ct + (long long)L * N, sin, glk, p, sp, ct, sin, L, 1, nb, ws, st);   // p0 = c0 + ks0
         launch_permute_coeff(c, perm, p, sp, out + (size_t)b0 * sout, sout, 2 * L, rm_seq(L), nb, st);
     });
 }
