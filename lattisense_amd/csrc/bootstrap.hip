@@ -590,14 +590,38 @@ struct Eval {
     }
     DCt mul_int(const DCt& a, long long k) { return mul_int_raw(a, k, a.scale); }
     DCt mul_const(const DCt& a, double cst, double const_scale) { return mul_int_raw(a, round_even(cst * const_scale), a.scale * const_scale); }
-    DCt add_const(const DCt& a, double cst) {
+    // per-row vectors over BOTH polynomials: [value for the L limbs of c0 | `second` for the L limbs of c1]
+    const u64* kvec2(long long k0, long long k1, int level, bool montgomery) {
+        const int L = level + 1;
+        std::vector<int> mods(2 * L);
+        std::vector<u64> vals(2 * L);
+        for (int p = 0; p < 2; p++)
+            for (int j = 0; j < L; j++) {
+                mods[p * L + j] = j;
+                const long long qq = (long long)c.T.mod[j];
+                long long r = (p == 0 ? k0 : k1) % qq;
+                if (r < 0) r += qq;
+                vals[p * L + j] = (u64)r;
+            }
+        const std::string name = std::string(montgomery ? "b2m" : "b2r") + std::to_string(level) + "_" + std::to_string(k0) + "_" + std::to_string(k1);
+        return montgomery ? c.const_vec(name, mods, vals) : c.raw_vec(name, vals);
+    }
+    RowMap rm_both(int level) const {
+        RowMap rm;
+        rm.period = 2 * (level + 1);
+        for (int p = 0; p < 2; p++)
+            for (int j = 0; j <= level; j++) rm.mod_of[p * (level + 1) + j] = (unsigned char)j;
+        return rm;
+    }
+    // a * factor + cst in every slot, one pass (factor 1: plain add_const)
+    DCt mul_int_add_const(const DCt& a, long long factor, double cst) {
         const long long k = round_even(cst * a.scale);
         DCt o = alloc(a.level, a.scale);
-        LSA_HIP(hipMemcpyAsync(o.data(), a.data(), (size_t)m * stride(a.level) * sizeof(u64), hipMemcpyDeviceToDevice, s));
-        launch_add_const(c, o.data(), stride(a.level), kvec(k, a.level, false), o.data(), stride(a.level), a.level + 1,
-                         rm2(a.level), m, s);
+        launch_add_const(c, a.data(), stride(a.level), kvec2(k, 0, a.level, false), o.data(), stride(a.level), 2 * (a.level + 1),
+                         rm_both(a.level), m, s, factor == 1 ? nullptr : kvec2(factor, factor, a.level, true));
         return o;
     }
+    DCt add_const(const DCt& a, double cst) { return mul_int_add_const(a, 1, cst); }
     // every polynomial times a shared plaintext (stride 0 over the batch)
     DCt mul_plain(const DCt& a, const u64* pt, double pt_scale) {
         DCt o = alloc(a.level, a.scale * pt_scale);
@@ -669,7 +693,7 @@ struct Eval {
         powers[1] = u;
         for (int j = 1; j < k; j++) {   // T_{2^j} = 2 T_{2^(j-1)}^2 - 1
             const DCt& p = powers[1 << (j - 1)];
-            powers[1 << j] = add_const(mul_int(mul(p, p), 2), -1.0);
+            powers[1 << j] = mul_int_add_const(mul(p, p), 2, -1.0);
         }
         std::function<DCt(const std::vector<double>&, int, double)> rec = [&](const std::vector<double>& cf, int level_out,
                                                                               double scale_out) -> DCt {
@@ -699,7 +723,7 @@ struct Eval {
 
     DCt eval_mod(const DCt& u) {
         DCt y = eval_chebyshev(u, bt.cheb);
-        for (int i = 0; i < bt.r; i++) y = add_const(mul_int(mul(y, y), 2), -1.0);
+        for (int i = 0; i < bt.r; i++) y = mul_int_add_const(mul(y, y), 2, -1.0);
         return y;
     }
 

@@ -293,11 +293,13 @@ void launch_muladd(Context& c, EwOp op, const u64* a, const u64* b, const u64* a
     LSA_HIP(hipGetLastError());
 }
 
-// out[b][row] = a[b][row] + kvec[row]: a real constant added to every slot is the same residue in every NTT coefficient of c0
+// out[b][row] = a[b][row] * mvec[row] + kvec[row]: a real constant added to every slot is the same residue in every NTT
+// coefficient of c0 (kvec: plain residues, one per row; mvec: optional Montgomery-form factors, null = 1)
 struct AddConstArgs {
     const u64* a;
     u64* out;
-    const u64* kvec;   // per row, plain residues
+    const u64* kvec;
+    const u64* mvec;
     long long sa, so;
     const ModDev* mods;
     int logn;
@@ -307,19 +309,26 @@ __global__ __launch_bounds__(TPB) void k_add_const(AddConstArgs g) {
     const int chunks = (1 << g.logn) / (2 * TPB);
     const int row = blockIdx.x / chunks;
     const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
-    const u64 q = g.mods[g.mod_of[row]].q, k = g.kvec[row];
+    const ModDev m = g.mods[g.mod_of[row]];
+    const u64 k = g.kvec[row];
     const long long b = blockIdx.y, off = ((long long)row << g.logn) + x;
-    const ulonglong2 v = ld2(g.a + b * g.sa + off);
-    st2(g.out + b * g.so + off, add_mod(v.x, k, q), add_mod(v.y, k, q));
+    ulonglong2 v = ld2(g.a + b * g.sa + off);
+    if (g.mvec) {
+        const u64 f = g.mvec[row];
+        v.x = mont_mul(v.x, f, m.q, m.qinv);
+        v.y = mont_mul(v.y, f, m.q, m.qinv);
+    }
+    st2(g.out + b * g.so + off, add_mod(v.x, k, m.q), add_mod(v.y, k, m.q));
 }
 void launch_add_const(Context& c, const u64* a, long long sa, const u64* kvec, u64* out, long long so, int rows,
-                      const RowMap& rm, int batch, hipStream_t s) {
+                      const RowMap& rm, int batch, hipStream_t s, const u64* mvec) {
     if (batch <= 0 || rows <= 0) return;
     LSA_REQUIRE(rm.period == rows && rows <= LSA_MAX_PERIOD, "add_const: row map must cover the rows");
     AddConstArgs g{};
     g.a = a;
     g.out = out;
     g.kvec = kvec;
+    g.mvec = mvec;
     g.sa = sa;
     g.so = so;
     g.mods = c.d_mods;

@@ -255,9 +255,9 @@ void launch_sub_mul_const(Context& c, const u64* a, long long sa, const u64* b, 
                           long long so, int rows, const RowMap& rm, int batch, hipStream_t s);
 void launch_mul_const(Context& c, const u64* a, long long sa, const u64* kvec, u64* out, long long so, int rows,
                       const RowMap& rm, int batch, hipStream_t s);
-// out[row] = a[row] + kvec[row] (plain residues, one per row)
+// out[row] = a[row] * mvec[row] + kvec[row] (kvec: plain residues, mvec: Montgomery-form factors or null)
 void launch_add_const(Context& c, const u64* a, long long sa, const u64* kvec, u64* out, long long so, int rows,
-                      const RowMap& rm, int batch, hipStream_t s);
+                      const RowMap& rm, int batch, hipStream_t s, const u64* mvec = nullptr);
 void launch_probe_copy(u64* dst, const u64* src, size_t n, hipStream_t s);
 void launch_probe_mulhi(u64* buf, size_t n, int iters, hipStream_t s);
 
