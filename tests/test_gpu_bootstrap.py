@@ -150,3 +150,56 @@ def test_sparse_slot_bootstrap_bit_exact_against_the_oracle_program():
     assert re >= 10 and im >= 10
     assert sorted(ev.glk) == sorted(plan.galois_elements)
     plan.close()
+
+
+def test_multiply_then_bootstrap_task():
+    """unittests/test_gpu_ckks.py:596-616 / test_gpu_ckks.cpp:783-808: mult+relin at level 3, rescale, drop to level 0,
+    bootstrap -- one task.  The relinearisation key is the level-24 one (used at level 3); the bootstrap is
+    plaintext-preserving, so the output keeps the product's scale (scale^2 / q_3), as the reference test declares it."""
+    need_gpu()
+    import json
+    import os
+    from lattisense_amd.device import ALGO_CKKS, BootstrapPlan, DeviceContext
+    from lattisense_amd.task import Argument, Ciphertext, FheTaskGpu, GaloisKey, KeySwitchKey
+    from oracle.ckks_bootstrap import Bootstrapper, Ct, Evaluator
+    from oracle.client import Client, mean_precision_bits
+    from oracle.pyoracle import Oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "tasks", "ckks_n2048_cmc_relin_rescale_bootstrap")
+    P = json.load(open(os.path.join(path, "mega_ag.json")))["parameter"]
+    sig = json.load(open(os.path.join(path, "task_signature.json")))
+    n, q, p, D = P["n"], P["q"], P["p"], float(P["scale"])
+    top, k, lvl = len(q) - 1, len(p), 3
+    o = Oracle(n, q, p, 0)
+    c, sparse = Client(o, seed=51), Client(o, seed=52, hamming=32)
+    ev = Evaluator(o, c, top)
+    keys = {int(e): c.gen_galois_key(int(e), top) for e in sig["key"]["glk"]}
+    ev.glk = dict(keys)
+    dts = c.gen_switching_key(c.s_ntt, sparse.s_ntt, 0)
+    std = c.gen_switching_key(sparse.s_ntt, c.s_ntt, top)
+    rng = np.random.default_rng(53)
+    xm = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(2)]
+    ym = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(2)]
+    xs = [c.ckks_encrypt(m, lvl, D) for m in xm]
+    ys = [c.ckks_encrypt(m, lvl, D) for m in ym]
+    t = FheTaskGpu(path)
+    zs = [Ciphertext.empty(1, P["btp_output_level"], n) for _ in range(2)]
+    t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
+           Argument("rlk_ntt", [KeySwitchKey(ev.rlk, top, k)]),
+           Argument("glk_ntt", [GaloisKey({e: KeySwitchKey(kk, top, k) for e, kk in keys.items()})]),
+           Argument("swk_dts", [KeySwitchKey(dts, 0, k)]), Argument("swk_std", [KeySwitchKey(std, top, k)])],
+          [Argument("out_z_list", zs)])
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    plan = BootstrapPlan(ctx, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
+                         P["btp_eval_mod_message_ratio"], D, D)
+    bt = Bootstrapper(ev, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
+                      P["btp_eval_mod_message_ratio"], out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev())
+    prod_scale = D * D / q[lvl]
+    for i in range(2):
+        z = o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], ev.rlk, top)[:, :1]          # level 2, dropped to level 0
+        want = bt.bootstrap(Ct(z, 0, D), top, dts, std)
+        assert np.array_equal(zs[i].data, want.data)
+        re, im = mean_precision_bits(xm[i] * ym[i], c.ckks_decrypt(zs[i].data, prod_scale))
+        assert re >= 10 and im >= 10
+    plan.close()
+    t.close()

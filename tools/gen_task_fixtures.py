@@ -154,6 +154,17 @@ def main():
     ys = [bootstrap(xs[i], f"y_{i}") for i in range(2)]
     emit("ckks_n2048_bootstrap", [Argument("in_x_list", xs)], [Argument("out_y_list", ys)])
 
+    # unittests/test_gpu_ckks.py:596-616: multiply at level 3, rescale, drop to level 0, bootstrap
+    bp = CkksBtpParam.create_toy_param()
+    bp.n = 2048
+    bp.slots = 1024
+    set_fhe_param(bp)
+    xs = [CkksCiphertextNode(f"x_{i}", level=3) for i in range(2)]
+    ys = [CkksCiphertextNode(f"y_{i}", level=3) for i in range(2)]
+    zs = [bootstrap(drop_level(rescale(mult_relin(xs[i], ys[i])), 2), f"result_{i}") for i in range(2)]
+    emit("ckks_n2048_cmc_relin_rescale_bootstrap", [Argument("in_x_list", xs), Argument("in_y_list", ys)],
+         [Argument("out_z_list", zs)])
+
     # application-shaped graph: packed conv2d, 1 -> 1 channels of 32x32, 3x3 kernel (two channel slots per ciphertext at N=4096)
     conv_fixture("ckks_n4096_conv2d_1in_1out_32x32_3x3", ckks_param(4096, 5), 4096, 1, 1, (32, 32), (3, 3), 2)
 
