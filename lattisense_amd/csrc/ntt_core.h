@@ -178,6 +178,9 @@ LSA_HD double fp_reduce(double x, double q, double qinv) { return __builtin_fma(
 // load->convert->ds_write loop serialises one HBM latency per step (measured with the LSA_NTT_DIAG_STAMPS build: 16.3k of
 // a workgroup's 34.6k cycles).
 #define LSA_NTT_STAGE_PAIRS 8   // 16-byte pairs per thread: supports tiles up to 2 * 8 * LSA_NTT_THREADS points
+#ifndef LSA_NTT_HEAD_ROUNDS
+#define LSA_NTT_HEAD_ROUNDS 2   // two-operand prologue: load rounds per tile (1 = all 16 operand pairs in flight at once)
+#endif
 struct NttLoadFix {   // per-block constants of the load-side conversions
     bool head, add, fp, near;
     u64 ql, h, hq;
@@ -242,7 +245,7 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
         return;
     }
     if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS) {   // two operands per element: half the pairs per round
-        constexpr int CH = LSA_NTT_STAGE_PAIRS / 2;
+        constexpr int CH = LSA_NTT_STAGE_PAIRS / LSA_NTT_HEAD_ROUNDS;
 #pragma unroll 1
         for (int p0 = 0; p0 < LSA_NTT_STAGE_PAIRS; p0 += CH) {
             u64 st[2 * CH], sl[2 * CH];

@@ -233,3 +233,41 @@ def test_engine_and_stream_variants_agree():
         ctx.set_tile_batch(tile)
         got = ctx.download(ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch), (batch, 2, lvl, n))
         assert np.array_equal(got, ref), (fp64, dual, tile)
+
+
+def test_headline_shape_full_size():
+    """BASELINE configs[2] at full size (N=2^16, 13 Q + 4 P limbs): the fused operator against the oracle on one ciphertext,
+    against the three separate operators, across butterfly engines / fused tails / operator tiles, and independent of the
+    position in the batch."""
+    need_gpu()
+    from lattisense_amd._native import check, lib
+    from lattisense_amd.device import DeviceContext, ALGO_CKKS
+    from oracle.pyoracle import Oracle
+    P = params.CKKS_DEFAULT[65536]
+    n, q, p = 65536, P["q"][:13], P["p"]
+    lvl = 12
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    rng = np.random.default_rng(2026)
+    batch = 5
+    A, Bc = rand_ct(rng, q, 2, n, batch), rand_ct(rng, q, 2, n, batch)
+    A[3], Bc[3] = A[0], Bc[0]                      # the same ciphertexts at two batch positions
+    beta = (lvl + 1 + len(p) - 1) // len(p)
+    key = np.empty((beta, 2, lvl + 1 + len(p), n), dtype=np.uint64)
+    for j, m in enumerate(q + p):
+        key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+    k = ctx.upload_key(key, lvl)
+    da, db = ctx.upload(A), ctx.upload(Bc)
+    ref = ctx.download(ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch), (batch, 2, lvl, n))
+    assert np.array_equal(ref[0], ref[3])
+    o = Oracle(n, q, p, 0)
+    assert np.array_equal(ref[1], o.ckks_mult_relin_rescale(lvl, A[1], Bc[1], key, lvl))
+    d3 = ctx.ckks_mult(lvl, da, db, batch)
+    r2 = ctx.ckks_relin(lvl, d3, k, batch)
+    sep = ctx.download(ctx.ckks_rescale(lvl, 2, r2, batch), (batch, 2, lvl, n))
+    assert np.array_equal(sep, ref)                # merged ModDown+rescale tail == the two tails one after the other
+    for fp64, fuse, tile in [(0, 1, 2), (1, 0, 5), (0, 0, 1)]:
+        ctx.set_fp64_ntt(fp64)
+        check(lib().lsa_set_fuse_tails(ctx.h, fuse))
+        ctx.set_tile_batch(tile)
+        got = ctx.download(ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch), (batch, 2, lvl, n))
+        assert np.array_equal(got, ref), (fp64, fuse, tile)
