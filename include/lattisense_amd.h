@@ -137,15 +137,16 @@ int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib);
  * of the level-0 input; out_scale: scale the refreshed ciphertext must have (0: whatever falls out).  The context's chain
  * must have cts_depth + 5 + double_angle + stc_depth levels above the output level.  log_slots: 0 or log2(N)-1 for dense
  * packing, smaller for sparsely packed ciphertexts (SubSum, one EvalMod on the packed real|imaginary halves, repacking
- * SlotsToCoeffs).  lsa_bootstrap_info reports n_cts negated for a sparse plan; its matrices are then ordered
- * [leading CoeffsToSlots ..., P1, P2, SlotsToCoeffs ...].
+ * SlotsToCoeffs).  The matrices of a sparse plan (lsa_bootstrap_info: sparse = 1) are ordered
+ * [n_cts leading CoeffsToSlots ..., P1, P2, SlotsToCoeffs ...], those of a dense plan [n_cts CoeffsToSlots, SlotsToCoeffs ...].
  * lsa_ckks_bootstrap: in [batch][2][1][N] -> out [batch][2][out_level+1][N]; swk_dts / swk_std (both or neither) are the
  * sparse-secret encapsulation keys at level 0 / top level (custom_task.py:1989-1996). */
 typedef struct lsa_bootstrap_st* lsa_bootstrap;
 int lsa_bootstrap_create(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
                          double in_scale, double out_scale, int log_slots, void* stream, lsa_bootstrap* out);
 void lsa_bootstrap_destroy(lsa_bootstrap b);
-int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* n_galois, int* n_matrices, int* n_cts);
+int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* n_galois, int* n_matrices, int* n_cts,
+                       int* sparse);
 int lsa_bootstrap_galois_elements(lsa_bootstrap b, uint64_t* out, int capacity);
 /* the plan's floating-point constants, exported so that a checker can replay the program with the same integers */
 int lsa_bootstrap_chebyshev(lsa_bootstrap b, double* out32);

@@ -81,7 +81,7 @@ SIGNATURES = {
                                      c_vp, ctypes.POINTER(c_vp)]),
     "lsa_bootstrap_destroy": (None, [c_vp]),
     "lsa_bootstrap_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
-                                   ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+                                   ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "lsa_bootstrap_galois_elements": (c_int, [c_vp, c_u64p, c_int]),
     "lsa_bootstrap_chebyshev": (c_int, [c_vp, ctypes.POINTER(ctypes.c_double)]),
     "lsa_bootstrap_matrix_info": (c_int, [c_vp, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),

@@ -364,14 +364,16 @@ void lsa_bootstrap_destroy(lsa_bootstrap b) {
     bootstrap_destroy(b->b);
     delete b;
 }
-int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* n_galois, int* n_matrices, int* n_cts) {
+int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* n_galois, int* n_matrices, int* n_cts,
+                       int* sparse) {
     return guard([&] {
         LSA_REQUIRE(b != nullptr, "null bootstrap handle");
         if (out_level) *out_level = bootstrap_out_level(*b->b);
         if (out_scale) *out_scale = bootstrap_out_scale(*b->b);
         if (n_galois) *n_galois = (int)bootstrap_galois(*b->b).size();
         if (n_matrices) *n_matrices = bootstrap_matrices(*b->b);
-        if (n_cts) *n_cts = bootstrap_cts_matrices(*b->b) * (bootstrap_is_sparse(*b->b) ? -1 : 1);   // negative: sparse packing
+        if (n_cts) *n_cts = bootstrap_cts_matrices(*b->b);
+        if (sparse) *sparse = bootstrap_is_sparse(*b->b) ? 1 : 0;
     });
 }
 int lsa_bootstrap_galois_elements(lsa_bootstrap b, uint64_t* out, int capacity) {

@@ -210,11 +210,11 @@ class BootstrapPlan:
         check(lib().lsa_bootstrap_create(ctx.h, cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale,
                                          log_slots, ctx.stream, ctypes.byref(h)))
         self.h = h
-        lv, sc, ng, nm, nc = ctypes.c_int(), ctypes.c_double(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lv, sc, ng, nm, nc, sp = ctypes.c_int(), ctypes.c_double(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(lib().lsa_bootstrap_info(self.h, ctypes.byref(lv), ctypes.byref(sc), ctypes.byref(ng), ctypes.byref(nm),
-                                       ctypes.byref(nc)))
+                                       ctypes.byref(nc), ctypes.byref(sp)))
         self.out_level, self.out_scale, self.n_matrices = lv.value, sc.value, nm.value
-        self.sparse, self.n_cts = nc.value < 0, abs(nc.value)
+        self.sparse, self.n_cts = bool(sp.value), nc.value
         g = (ctypes.c_uint64 * ng.value)()
         check(lib().lsa_bootstrap_galois_elements(self.h, g, ng.value))
         self.galois_elements = [int(x) for x in g]
