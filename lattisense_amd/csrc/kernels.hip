@@ -47,8 +47,11 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
 }
 
 // FZ: the launch carries a fused prologue/epilogue (NttPassArgs::fz_*)
+#ifndef LSA_NTT_WAVES_FUSED
+#define LSA_NTT_WAVES_FUSED LSA_NTT_WAVES
+#endif
 template <bool FZ>
-__global__ __launch_bounds__(LSA_NTT_THREADS, LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
+__global__ __launch_bounds__(LSA_NTT_THREADS, FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
 #if LSA_NTT_TILES_PER_WG == 1
