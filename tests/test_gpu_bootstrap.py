@@ -69,11 +69,12 @@ def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate):
     plan.close()
 
 
-def test_bootstrap_node_through_the_task_boundary():
-    """A task compiled by the reference's frontend from its toy bootstrap parameter set (ring reduced to N=2048 for the CPU
-    oracle): one `bootstrap` node per ciphertext, keys rlk / 22 column rotations / conjugation / swk_dts / swk_std as the
-    frontend lists them.  Through run_fhe_gpu_task: level 0 -> 9, >= 10 bits, and identical to the oracle program fed with the
-    constants of an operator-level plan built from the same parameters."""
+@pytest.mark.parametrize("fixture", ["ckks_n2048_bootstrap", "ckks_n2048_slots512_bootstrap"])
+def test_bootstrap_node_through_the_task_boundary(fixture):
+    """Tasks compiled by the reference's frontend from its toy bootstrap parameter set (ring reduced to N=2048 for the CPU
+    oracle), densely and sparsely packed: one `bootstrap` node per ciphertext, keys rlk / column rotations / conjugation /
+    swk_dts / swk_std as the frontend lists them.  Through run_fhe_gpu_task: level 0 -> 9, >= 10 bits, and identical to the
+    oracle program fed with the constants of an operator-level plan built from the same parameters."""
     need_gpu()
     import json
     import os
@@ -83,7 +84,8 @@ def test_bootstrap_node_through_the_task_boundary():
     from oracle.client import Client, mean_precision_bits
     from oracle.pyoracle import Oracle
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "tests", "golden", "tasks", "ckks_n2048_bootstrap")
+    from oracle.ckks_bootstrap import SparseBootstrapper
+    path = os.path.join(root, "tests", "golden", "tasks", fixture)
     P = json.load(open(os.path.join(path, "mega_ag.json")))["parameter"]
     sig = json.load(open(os.path.join(path, "task_signature.json")))
     n, q, p, D = P["n"], P["q"], P["p"], float(P["scale"])
@@ -96,8 +98,10 @@ def test_bootstrap_node_through_the_task_boundary():
     dts = c.gen_switching_key(c.s_ntt, sparse.s_ntt, 0)
     std = c.gen_switching_key(sparse.s_ntt, c.s_ntt, top)
     rng = np.random.default_rng(43)
-    zs = [rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2) for _ in range(2)]
-    cts = [c.ckks_encrypt(z, 0, D) for z in zs]
+    ns = P["slots"]
+    sparse = ns < n // 2
+    zs = [rng.uniform(-1, 1, ns) + 1j * rng.uniform(-1, 1, ns) for _ in range(2)]
+    cts = [c.ckks_encrypt(np.tile(z, (n // 2) // ns), 0, D) for z in zs]
     t = FheTaskGpu(path)
     ys = [Ciphertext.empty(1, P["btp_output_level"], n) for _ in range(2)]
     t.run([Argument("in_x_list", [Ciphertext(x) for x in cts]), Argument("rlk_ntt", [KeySwitchKey(ev.rlk, top, k)]),
@@ -107,12 +111,15 @@ def test_bootstrap_node_through_the_task_boundary():
     assert t.last_run_stats()["gpu_batches"] == 1                       # both bootstraps in one batched program
     ctx = DeviceContext(ALGO_CKKS, n, q, p)
     plan = BootstrapPlan(ctx, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
-                         P["btp_eval_mod_message_ratio"], D, D)
+                         P["btp_eval_mod_message_ratio"], D, D, log_slots=ns.bit_length() - 1)
     plains = plan.oracle_plains()
-    bt = Bootstrapper(ev, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
-                      P["btp_eval_mod_message_ratio"], out_scale=D, plains=plains, coeffs=plan.chebyshev())
+    cfg = (P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"], P["btp_eval_mod_message_ratio"])
+    if sparse:
+        bt = SparseBootstrapper(ev, ns.bit_length() - 1, *cfg, out_scale=D, plains=plains, coeffs=plan.chebyshev())
+    else:
+        bt = Bootstrapper(ev, *cfg, out_scale=D, plains=plains, coeffs=plan.chebyshev())
     for i in range(2):
-        re, im = mean_precision_bits(zs[i], c.ckks_decrypt(ys[i].data, D))
+        re, im = mean_precision_bits(zs[i], c.ckks_decrypt(ys[i].data, D)[:ns])
         assert re >= 10 and im >= 10
         assert np.array_equal(ys[i].data, bt.bootstrap(Ct(cts[i], 0, D), top, dts, std).data)
     plan.close()

@@ -154,6 +154,15 @@ def main():
     ys = [bootstrap(xs[i], f"y_{i}") for i in range(2)]
     emit("ckks_n2048_bootstrap", [Argument("in_x_list", xs)], [Argument("out_y_list", ys)])
 
+    # sparsely packed bootstrap (unittests/test_gpu_ckks.py:618-646: the toy sparse set): 2^9 of the 2^10 slots
+    bp = CkksBtpParam.create_toy_param()
+    bp.n = 2048
+    bp.slots = 512
+    set_fhe_param(bp)
+    xs = [CkksCiphertextNode(f"x_{i}", level=0) for i in range(2)]
+    ys = [bootstrap(xs[i], f"y_{i}") for i in range(2)]
+    emit("ckks_n2048_slots512_bootstrap", [Argument("in_x_list", xs)], [Argument("out_y_list", ys)])
+
     # unittests/test_gpu_ckks.py:596-616: multiply at level 3, rescale, drop to level 0, bootstrap
     bp = CkksBtpParam.create_toy_param()
     bp.n = 2048
