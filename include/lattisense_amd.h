@@ -129,6 +129,11 @@ int lsa_set_fuse_tails(lsa_context ctx, int enable);
 /* Two-pass NTTs (N > 2^12) run both passes over a chunk of at most `mib` MiB of limbs before moving on, so that the
  * second pass is served by the 256 MiB Infinity Cache (0 = one launch per pass over the whole batch). */
 int lsa_set_ntt_chunk_mib(lsa_context ctx, int mib);
+/* Rotations of the same ciphertexts by several Galois elements with ONE decomposition of the input ("hoisting"):
+ * outs[i] = rotate(in, galois_elements[i]), each bit-identical to lsa_ckks_rotate's result. */
+int lsa_ckks_rotate_many(lsa_context ctx, int level, const uint64_t* in, int n_rot, const uint64_t* galois_elements,
+                         const lsa_key* glk, uint64_t* const* outs, int batch, long long sin, long long sout, void* stream);
+
 /* ---- CKKS bootstrapping: the `bootstrap` node of a task graph (reference: mega_ag_executors_gpu.cu:410-426 calls HEonGPU's
  * regular_bootstrapping_v2; configuration gpu_wrapper.cu:86-117 / custom_task.py:383-468).  A plan holds the encoded
  * CoeffsToSlots / SlotsToCoeffs diagonals (depths cts_depth / stc_depth, full-slot encoding), the EvalMod constants

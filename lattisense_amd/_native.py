@@ -77,6 +77,8 @@ SIGNATURES = {
     "lsa_set_fuse_tails": (c_int, [c_vp, c_int]),
     "lsa_set_ntt_chunk_mib": (c_int, [c_vp, c_int]),
     "lsa_debug_set_ntt_stamps": (c_int, [c_vp, c_vp]),
+    "lsa_ckks_rotate_many": (c_int, [c_vp, c_int, c_vp, c_int, c_u64p, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_int,
+                                     ctypes.c_longlong, ctypes.c_longlong, c_vp]),
     "lsa_bootstrap_create": (c_int, [c_vp, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int,
                                      c_vp, ctypes.POINTER(c_vp)]),
     "lsa_bootstrap_destroy": (None, [c_vp]),

@@ -7,6 +7,8 @@ void ckks_mult(Context&, int, const u64*, const u64*, u64*, int, long long, long
 void ckks_relin(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
 void ckks_rescale(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
 void ckks_rotate(Context&, int, const u64*, u64, const Key&, u64*, int, long long, long long, hipStream_t);
+void ckks_rotate_many(Context&, int, const u64*, int, const u64*, const Key* const*, u64* const*, int, long long, long long,
+                      hipStream_t);
 void ckks_mult_relin_rescale(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long,
                              long long, hipStream_t);
 void drop_level(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
@@ -340,6 +342,19 @@ int lsa_set_dual_stream(lsa_context ctx, int enable) {
 }
 int lsa_debug_set_ntt_stamps(lsa_context ctx, void* device_buffer) {
     return guard([&] { C(ctx).ntt_diag = static_cast<unsigned long long*>(device_buffer); });
+}
+
+int lsa_ckks_rotate_many(lsa_context ctx, int level, const uint64_t* in, int n_rot, const uint64_t* galois_elements,
+                         const lsa_key* glk, uint64_t* const* outs, int batch, long long sin, long long sout, void* stream) {
+    return guard([&] {
+        LSA_REQUIRE(in != nullptr && n_rot >= 0 && (n_rot == 0 || (galois_elements && glk && outs)), "null argument");
+        std::vector<const Key*> keys(n_rot);
+        for (int i = 0; i < n_rot; i++) {
+            LSA_REQUIRE(glk[i] != nullptr && outs[i] != nullptr, "null key or output");
+            keys[i] = &K(glk[i]);
+        }
+        ckks_rotate_many(C(ctx), level, in, n_rot, galois_elements, keys.data(), outs, batch, sin, sout, S(stream));
+    });
 }
 
 // ---- CKKS bootstrapping

@@ -141,6 +141,17 @@ class DeviceContext:
                                      polys * level * self.n, self.stream))
         return out
 
+    def ckks_rotate_many(self, level, ct, keys, batch):
+        """keys: {galois element: key handle}; returns {element: device buffer}, one decomposition for all (hoisted)"""
+        L = level + 1
+        outs = {g: self.alloc(batch * 2 * L * self.n) for g in keys}
+        els = (ctypes.c_uint64 * len(keys))(*keys.keys())
+        hk = (ctypes.c_void_p * len(keys))(*[k.value for k in keys.values()])
+        po = (ctypes.c_void_p * len(keys))(*[o.ptr for o in outs.values()])
+        check(lib().lsa_ckks_rotate_many(self.h, level, ct.ptr, len(keys), els, hk, po, batch, 2 * L * self.n, 2 * L * self.n,
+                                         self.stream))
+        return outs
+
     def ckks_rotate(self, level, ct, g, glk, batch):
         L = level + 1
         out = self.alloc(batch * 2 * L * self.n)

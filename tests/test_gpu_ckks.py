@@ -271,3 +271,34 @@ def test_headline_shape_full_size():
         ctx.set_tile_batch(tile)
         got = ctx.download(ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch), (batch, 2, lvl, n))
         assert np.array_equal(got, ref), (fp64, fuse, tile)
+
+
+def test_hoisted_rotations_equal_stand_alone_rotations():
+    """lsa_ckks_rotate_many: one decomposition of the input for several Galois elements; with the automorphism applied after
+    the key switch every output is bit-identical to lsa_ckks_rotate (and hence to the oracle)."""
+    need_gpu()
+    from lattisense_amd.device import DeviceContext, ALGO_CKKS
+    P = params.CKKS_DEFAULT[65536]
+    n, q, p = 8192, P["q"][:6], P["p"][:2]
+    lvl, klvl = 3, 5
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    rng = np.random.default_rng(91)
+    batch = 3
+    A = rand_ct(rng, q[: lvl + 1], 2, n, batch)
+    da = ctx.upload(A)
+    beta = (klvl + 1 + len(p) - 1) // len(p)
+    keys, raw = {}, {}
+    for g in (5, pow(5, 77, 2 * n), 2 * n - 1):
+        key = np.empty((beta, 2, klvl + 1 + len(p), n), dtype=np.uint64)
+        for j, m in enumerate(q + p):
+            key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+        raw[g] = key
+        keys[g] = ctx.upload_key(key, klvl)
+    outs = ctx.ckks_rotate_many(lvl, da, keys, batch)
+    from oracle.pyoracle import Oracle
+    o = Oracle(n, q, p, 0)
+    for g in keys:
+        got = ctx.download(outs[g], (batch, 2, lvl + 1, n))
+        single = ctx.download(ctx.ckks_rotate(lvl, da, g, keys[g], batch), (batch, 2, lvl + 1, n))
+        assert np.array_equal(got, single)
+        assert np.array_equal(got[1], o.ckks_rotate(lvl, A[1], g, raw[g], klvl))
