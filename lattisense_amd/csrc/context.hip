@@ -41,13 +41,13 @@ Context::Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_
     use_device();
     const size_t tw_bytes = (size_t)nmod * n * sizeof(u64);
     LSA_HIP(hipMalloc((void**)&d_mods, nmod * sizeof(ModDev)));
-    LSA_HIP(hipMalloc((void**)&d_psi, tw_bytes));
-    LSA_HIP(hipMalloc((void**)&d_psiinv, tw_bytes));
-    LSA_HIP(hipMalloc((void**)&d_scale, (size_t)nmod * 2 * sizeof(u64)));
+    LSA_HIP(hipMalloc((void**)&d_psi, 2 * tw_bytes));      // {w, Shoup quotient} pairs
+    LSA_HIP(hipMalloc((void**)&d_psiinv, 2 * tw_bytes));
+    LSA_HIP(hipMalloc((void**)&d_scale, (size_t)nmod * 4 * sizeof(u64)));
     LSA_HIP(hipMemcpy(d_mods, T.mods.data(), nmod * sizeof(ModDev), hipMemcpyHostToDevice));
-    LSA_HIP(hipMemcpy(d_psi, T.psi.data(), tw_bytes, hipMemcpyHostToDevice));
-    LSA_HIP(hipMemcpy(d_psiinv, T.psiinv.data(), tw_bytes, hipMemcpyHostToDevice));
-    LSA_HIP(hipMemcpy(d_scale, T.scale.data(), (size_t)nmod * 2 * sizeof(u64), hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_psi, T.psi.data(), 2 * tw_bytes, hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_psiinv, T.psiinv.data(), 2 * tw_bytes, hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_scale, T.scale.data(), (size_t)nmod * 4 * sizeof(u64), hipMemcpyHostToDevice));
     LSA_HIP(hipMalloc((void**)&d_psi_d, tw_bytes));
     LSA_HIP(hipMalloc((void**)&d_psiinv_d, tw_bytes));
     LSA_HIP(hipMalloc((void**)&d_scale_d, (size_t)nmod * 2 * sizeof(double)));

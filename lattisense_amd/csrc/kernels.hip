@@ -1122,7 +1122,36 @@ __global__ __launch_bounds__(TPB) void k_probe_mulhi(u64* buf, size_t n, int ite
     buf[4 * i + 2] = c;
     buf[4 * i + 3] = d;
 }
+// the same chains with Shoup/Harvey multiplication by a constant with precomputed quotient w' = floor(w*2^64/q):
+// r = w*v - mulhi(w', v)*q  (mod 2^64), in [0, 2q)
+__device__ __forceinline__ u64 shoup_mul_lazy(u64 v, u64 w, u64 wq, u64 q) {
+    const u64 t = mulhi64(wq, v);
+    return mul_lo64(w, v) - mul_lo64(t, q);
+}
+__global__ __launch_bounds__(TPB) void k_probe_shoup(u64* buf, size_t n, int iters) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i * 4 + 3 >= n) return;
+    const u64 q = 0x1FFFFFFFFFE00001ull;
+    u64 a = buf[4 * i], b = buf[4 * i + 1], c = buf[4 * i + 2], d = buf[4 * i + 3];
+    const u64 w = a | 1, wq = b | 1;
+    for (int it = 0; it < iters; it++) {
+        a = shoup_mul_lazy(a, w, wq + it, q);
+        b = shoup_mul_lazy(b, w, wq + it, q);
+        c = shoup_mul_lazy(c, w, wq + it, q);
+        d = shoup_mul_lazy(d, w, wq + it, q);
+    }
+    buf[4 * i] = a;
+    buf[4 * i + 1] = b;
+    buf[4 * i + 2] = c;
+    buf[4 * i + 3] = d;
+}
 void launch_probe_mulhi(u64* buf, size_t n, int iters, hipStream_t s) {
+    if (iters < 0) {   // negative: the Shoup variant
+        const size_t threads = n / 4;
+        hipLaunchKernelGGL(k_probe_shoup, dim3((unsigned)((threads + TPB - 1) / TPB)), dim3(TPB), 0, s, buf, n, -iters);
+        LSA_HIP(hipGetLastError());
+        return;
+    }
     const size_t threads = n / 4;
     hipLaunchKernelGGL(k_probe_mulhi, dim3((unsigned)((threads + TPB - 1) / TPB)), dim3(TPB), 0, s, buf, n, iters);
     LSA_HIP(hipGetLastError());

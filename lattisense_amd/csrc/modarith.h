@@ -87,7 +87,16 @@ LSA_HD u64 mont_mul_lazy(u64 a, u64 b, u64 q, u64 qinv) {
     const U128 p = mul_wide(a, b);
     return mont_redc_lazy(p.hi, p.lo, q, qinv);
 }
+// Shoup / Harvey multiplication by a constant w < q with its precomputed quotient ws = floor(w * 2^64 / q):
+// w*v - mulhi(ws, v)*q (mod 2^64) is w*v mod q in [0, 2q) for any 64-bit v.  Measured on gfx950 (tools/probe_mul.py):
+// 2.65e12 against 1.66e12 Montgomery multiplies per second -- the low halves of two products cost less than REDC's.
+LSA_HD u64 shoup_mul_lazy(u64 v, u64 w, u64 ws, u64 q);
+// (measured and dropped: flag-free formulations of the 64-bit compare/select and subtract -- sign masks, a + ~b + 1 through
+// v_lshl_add_u64 -- remove the VCC hazards hipcc's lowering has, but the extra register moves cost more: integer engine
+// 1.63 -> 1.27 TB/s)
+LSA_HD u64 sub64(u64 a, u64 b) { return a - b; }
 LSA_HD u64 csub(u64 a, u64 q) { return a >= q ? a - q : a; }
+LSA_HD u64 shoup_mul_lazy(u64 v, u64 w, u64 ws, u64 q) { return sub64(mul_lo64(w, v), mul_lo64(mulhi64(ws, v), q)); }
 // a*b*2^-64 mod q in [0,q)
 LSA_HD u64 mont_mul(u64 a, u64 b, u64 q, u64 qinv) { return csub(mont_mul_lazy(a, b, q, qinv), q); }
 // plain a*b mod q for a,b in [0,q): two REDCs (a*b*R^-1, then *R^2*R^-1)

@@ -48,8 +48,8 @@ struct NttPassArgs {
     long long total_tiles;   // batch * rows * tiles-per-limb
     int rows;             // limb-polynomials per batch item, each N contiguous elements
     const ModDev* mods;   // [nmod]
-    const u64* tw;        // [nmod][N] Montgomery-form psi^{brv(x)} (forward) or psi^{-brv(x)} (inverse)
-    const u64* scale;     // [nmod][2] inverse only: {N^-1 * R, psiinv[1] * N^-1 * R}
+    const u64* tw;        // [nmod][N][2] {w, Shoup quotient of w}, w = psi^{brv(x)} (forward) or psi^{-brv(x)} (inverse)
+    const u64* scale;     // [nmod][2][2] inverse only: the same pairs for N^-1 and psiinv[1] * N^-1
     const double* twd;    // [nmod][N] the same twiddles as plain doubles (FP64 engine)
     const double* scaled; // [nmod][2]
     int logn, s_lo, mu, lambda, tau;
@@ -433,12 +433,13 @@ template <int RHO, bool LIN>
 LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const ModDev md = a.mods[bc.mod];
-    const u64 q = md.q, qinv = md.qinv, q2 = 2 * md.q;
-    const u64* tw = a.tw + ((long long)bc.mod << a.logn);
+    const u64 q = md.q, q2 = 2 * md.q;
+    const u64* tw = a.tw + (((long long)bc.mod << a.logn) << 1);   // {w, ws} pairs
     const int beta0 = a.lambda + a.mu - sig0 - RHO;  // lowest active bit of this sub-pass in l
     const int ngroups = 1 << (a.tau - RHO);
     const bool scale_here = a.inverse && a.apply_scale && a.s_lo + sig0 == 0;
-    const u64 sc0 = scale_here ? a.scale[2 * bc.mod] : 0, sc1 = scale_here ? a.scale[2 * bc.mod + 1] : 0;
+    const u64* sc = a.scale + 4 * bc.mod;
+    const u64 sc0 = scale_here ? sc[0] : 0, sc0s = scale_here ? sc[1] : 0, sc1 = scale_here ? sc[2] : 0, sc1s = scale_here ? sc[3] : 0;
     for (int gid = tid; gid < ngroups; gid += LSA_NTT_THREADS) {
         int lbase = ((gid >> beta0) << (beta0 + RHO)) | (gid & ((1 << beta0) - 1));
         const int ad0 = lds_addr(lbase), adst = !LIN ? 0 : beta0 ? (1 << beta0) + (1 << (beta0 - 4)) : 1;
@@ -454,15 +455,15 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
             for (int j = 0; j < RHO; j++) {
                 const int half = E >> (j + 1);
                 const int s = a.s_lo + sig0 + j;
-                const u64* twj = tw + (1 << s) + ((long long)G << j);
+                const u64* twj = tw + 2 * ((1 << s) + ((long long)G << j));
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
-                        u64 w = twj[e >> (RHO - j)];
+                        const int ti = 2 * (e >> (RHO - j));
                         u64 U = csub(v[e], q2);
-                        u64 T = mont_mul_lazy(v[e + half], w, q, qinv);
+                        u64 T = shoup_mul_lazy(v[e + half], twj[ti], twj[ti + 1], q);
                         v[e] = U + T;
-                        v[e + half] = U + q2 - T;
+                        v[e + half] = sub64(U + q2, T);
                     }
                 }
             }
@@ -471,22 +472,23 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
             for (int j = RHO - 1; j >= 0; j--) {
                 const int half = E >> (j + 1);
                 const int s = a.s_lo + sig0 + j;
-                const u64* twj = tw + (1 << s) + ((long long)G << j);
+                const u64* twj = tw + 2 * ((1 << s) + ((long long)G << j));
                 if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
 #pragma unroll
                     for (int e = 0; e < half; e++) {
                         u64 U = v[e], V = v[e + half];   // both in [0,2q)
-                        v[e] = mont_mul_lazy(U + V, sc0, q, qinv);
-                        v[e + half] = mont_mul_lazy(U + q2 - V, sc1, q, qinv);
+                        v[e] = shoup_mul_lazy(U + V, sc0, sc0s, q);
+                        v[e + half] = shoup_mul_lazy(sub64(U + q2, V), sc1, sc1s, q);
                     }
                     continue;
                 }
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
+                        const int ti = 2 * (e >> (RHO - j));
                         u64 U = v[e], V = v[e + half];   // both in [0,2q)
                         v[e] = csub(U + V, q2);
-                        v[e + half] = mont_mul_lazy(U + q2 - V, twj[e >> (RHO - j)], q, qinv);
+                        v[e + half] = shoup_mul_lazy(sub64(U + q2, V), twj[ti], twj[ti + 1], q);
                     }
                 }
             }

@@ -153,9 +153,9 @@ void HostTables::build(int n_, const std::vector<u64>& moduli) {
     mod = moduli;
     const size_t nm = mod.size();
     mods.resize(nm);
-    psi.assign(nm * (size_t)n, 0);
-    psiinv.assign(nm * (size_t)n, 0);
-    scale.assign(nm * 2, 0);
+    psi.assign(nm * (size_t)n * 2, 0);
+    psiinv.assign(nm * (size_t)n * 2, 0);
+    scale.assign(nm * 4, 0);
     psi_d.assign(nm * (size_t)n, 0.0);
     psiinv_d.assign(nm * (size_t)n, 0.0);
     scale_d.assign(nm * 2, 0.0);
@@ -176,12 +176,14 @@ void HostTables::build(int n_, const std::vector<u64>& moduli) {
         const u64 ps = pow_mod(g, (q - 1) / (2 * (u64)n), q);
         const u64 psi_inv = inv_mod(ps, q);
         u64 pw = 1, pwi = 1;
-        u64* t = &psi[i * (size_t)n];
-        u64* ti = &psiinv[i * (size_t)n];
+        u64* t = &psi[i * (size_t)n * 2];
+        u64* ti = &psiinv[i * (size_t)n * 2];
         for (int j = 0; j < n; j++) {
             unsigned x = bit_reverse((unsigned)j, logn);
-            t[x] = to_mont_host(pw, q);
-            ti[x] = to_mont_host(pwi, q);
+            t[2 * x] = pw;
+            t[2 * x + 1] = shoup_quotient_host(pw, q);
+            ti[2 * x] = pwi;
+            ti[2 * x + 1] = shoup_quotient_host(pwi, q);
             if ((q >> 53) == 0) {  // exactly representable; only consumed when q < 2^47
                 psi_d[i * (size_t)n + x] = (double)pw;
                 psiinv_d[i * (size_t)n + x] = (double)pwi;
@@ -190,10 +192,12 @@ void HostTables::build(int n_, const std::vector<u64>& moduli) {
             pwi = mul_mod_host(pwi, psi_inv, q);
         }
         const u64 ninv = inv_mod((u64)n % q, q);
-        scale[2 * i] = to_mont_host(ninv, q);
+        scale[4 * i] = ninv;
+        scale[4 * i + 1] = shoup_quotient_host(ninv, q);
         // psiinv[1] = psi^{-brv(1)} = psi^{-n/2}
         u64 w1 = pow_mod(psi_inv, (u64)n / 2, q);
-        scale[2 * i + 1] = to_mont_host(mul_mod_host(w1, ninv, q), q);
+        scale[4 * i + 2] = mul_mod_host(w1, ninv, q);
+        scale[4 * i + 3] = shoup_quotient_host(scale[4 * i + 2], q);
         if ((q >> 53) == 0) {
             scale_d[2 * i] = (double)ninv;
             scale_d[2 * i + 1] = (double)mul_mod_host(w1, ninv, q);

@@ -21,14 +21,16 @@ struct HostTables {
     int n = 0, logn = 0;
     std::vector<u64> mod;       // all moduli: Q chain, then P, then BFV aux
     std::vector<ModDev> mods;   // Montgomery constants per modulus
-    std::vector<u64> psi;       // [nmod][n]  psi^{brv(x)} * 2^64 mod q
-    std::vector<u64> psiinv;    // [nmod][n]  psi^{-brv(x)} * 2^64 mod q
-    std::vector<u64> scale;     // [nmod][2]  {n^-1 * 2^64, psiinv[1] * n^-1 * 2^64} mod q
+    // integer engine: every twiddle w with its Shoup quotient floor(w * 2^64 / q), interleaved {w, ws}
+    std::vector<u64> psi;       // [nmod][n][2]  w = psi^{brv(x)}
+    std::vector<u64> psiinv;    // [nmod][n][2]  w = psi^{-brv(x)}
+    std::vector<u64> scale;     // [nmod][2][2]  w = n^-1 and psiinv[1] * n^-1 (the inverse transform's last stage)
     // the same tables as plain integer-valued doubles for the FP64 butterfly engine (used for q < 2^47 only)
     std::vector<double> psi_d, psiinv_d, scale_d;
     void build(int n_, const std::vector<u64>& moduli);
 };
 
 inline u64 to_mont_host(u64 a, u64 q) { return (u64)(((unsigned __int128)a << 64) % q); }
+inline u64 shoup_quotient_host(u64 a, u64 q) { return (u64)(((unsigned __int128)a << 64) / q); }
 
 }  // namespace lsa
