@@ -210,7 +210,13 @@ std::vector<double> slots_to_coeffs(std::vector<cplx> v, const std::vector<int>&
     return out;
 }
 
-long long round_even(double v) { return (long long)std::nearbyint(v); }   // Python's round(): ties to even
+// Python's round(): ties to even.  A constant beyond 2^62 means the modulus chain does not fit the level plan (e.g. EvalMod
+// running on primes much smaller than its scale): refuse instead of computing garbage.
+long long round_even(double v) {
+    LSA_REQUIRE(std::fabs(v) < 4.6e18, "bootstrap: encoded constant out of range -- the modulus chain does not match the "
+                                       "bootstrap level plan (depths / scales)");
+    return (long long)std::nearbyint(v);
+}
 
 }  // namespace
 

@@ -103,6 +103,7 @@ class Evaluator:
 
     def mul_const(self, a, c, const_scale):
         """times the real constant c encoded as round(c * const_scale); no rescale"""
+        assert abs(c * const_scale) < 4.6e18, "constant out of range: the modulus chain does not match the level plan"
         k = int(round(c * const_scale))
         return Ct(self._limbs(a, lambda pl, j, x: self.o.vec("mul", j, x, self._const(k, j))), a.level, a.scale * const_scale)
 
