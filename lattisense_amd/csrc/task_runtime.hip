@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <functional>
+#include <future>
 #include <optional>
 #include <cstdlib>
 #include <cstring>
@@ -1171,65 +1172,92 @@ struct fhe_task_handle_st {
                 StoreJob job;
                 std::vector<std::shared_ptr<Slab>> keep;
             };
-            auto finish = [&](InFlight& f) {
-                if (f.chunk < 0) return;
-                cur_lane = f.lane;
-                Context& lc = f.lane ? c1 : c;
-                hipStream_t ls = f.lane ? s1 : s;
-                auto t0 = tick();
-                LSA_HIP(hipStreamSynchronize(ls));
-                const double t_wait = ms_since(t0);
-                pending_free().clear();
-                f.keep.clear();
-                auto& cl = chunk_levels[f.chunk];
-                t0 = tick();
-                stores_finish(lc, f.job, avail);
-                {   // the store level's bookkeeping, then the CPU-side tail (import executors)
-                    release_inputs(cl[f.resume_level]);
-                    progress(cl[f.resume_level].size());
-                }
-                for (size_t l = f.resume_level + 1; l < cl.size(); l++) {
-                    if (cl[l].empty()) continue;
-                    Split sp = split(cl[l]);
-                    LSA_REQUIRE(sp.loads.empty() && sp.stores.empty() && sp.bucket_order.empty(), "pipeline plan violated");
-                    run_cpu_nodes(sp.cpu, avail, out_handles);
-                    release_inputs(cl[l]);
-                    progress(cl[l].size());
-                }
-                if (trace) fprintf(stderr, "[lsa task] chunk %d lane %d: waited %.2f ms, import %.2f ms\n", f.chunk, f.lane, t_wait, ms_since(t0));
-                f.chunk = -1;
+            // finish(): wait for the chunk's stream, wrap the results into C structs, run the import executors.  It runs on
+            // its own thread while the main thread stages and enqueues the next chunk, and touches no shared container: the
+            // structs live in a local map (only the import nodes read them), the per-lane temporaries are released by this
+            // thread while the main thread is, by construction, busy with the OTHER lane, and the progress counter has its
+            // own lock.
+            std::mutex progress_mu;
+            auto progress_locked = [&](size_t nodes_done) {
+                std::lock_guard<std::mutex> lk(progress_mu);
+                progress(nodes_done);
             };
-            InFlight fly[2];
-            for (size_t ch = 0; ch < chunk_levels.size(); ch++) {
-                const int lane = (int)(ch & 1);
-                finish(fly[lane]);            // the lane's previous chunk (two chunks in flight at most)
-                cur_lane = lane;
+            auto finish = [&](InFlight* f) {
+                const int lane = f->lane;
                 Context& lc = lane ? c1 : c;
                 hipStream_t ls = lane ? s1 : s;
                 lc.use_device();
-                InFlight& f = fly[lane];
-                f.chunk = (int)ch;
-                f.lane = lane;
-                auto& cl = chunk_levels[ch];
                 auto t0 = tick();
-                for (size_t l = 0; l < cl.size(); l++) {
+                LSA_HIP(hipStreamSynchronize(ls));
+                const double t_wait = ms_since(t0);
+                pending_free_[lane].clear();
+                f->keep.clear();
+                auto& cl = chunk_levels[f->chunk];
+                t0 = tick();
+                std::unordered_map<NodeIndex, std::any> local;
+                stores_finish(lc, f->job, local);
+                f->job = StoreJob{};
+                progress_locked(cl[f->resume_level].size());
+                for (size_t l = f->resume_level + 1; l < cl.size(); l++) {
                     if (cl[l].empty()) continue;
                     Split sp = split(cl[l]);
-                    if (!sp.stores.empty()) {     // copy-out enqueued; the rest of the chunk happens in finish()
-                        f.job = stores_enqueue(lc, ls, sp.stores, avail);
-                        f.resume_level = l;
-                        break;
-                    }
-                    if (!sp.cpu.empty()) run_cpu_nodes(sp.cpu, avail, out_handles);   // export executors
-                    if (!sp.loads.empty()) f.keep.push_back(run_loads(lc, ls, sp.loads, avail));
-                    run_buckets(lc, ls, sp.buckets, sp.bucket_order, avail);
-                    release_inputs(cl[l]);
-                    progress(cl[l].size());
+                    LSA_REQUIRE(sp.loads.empty() && sp.stores.empty() && sp.bucket_order.empty(), "pipeline plan violated");
+                    run_cpu_nodes(sp.cpu, local, out_handles);
+                    progress_locked(cl[l].size());
                 }
-                if (trace) fprintf(stderr, "[lsa task] chunk %zu lane %d: enqueued in %.2f ms\n", ch, lane, ms_since(t0));
+                if (trace) fprintf(stderr, "[lsa task] chunk %d lane %d: waited %.2f ms, import %.2f ms\n", f->chunk, lane, t_wait, ms_since(t0));
+                f->chunk = -1;
+            };
+            InFlight fly[2];
+            std::future<void> done[2];
+            auto join = [&](int lane) {
+                if (done[lane].valid()) done[lane].get();   // rethrows what the finisher threw
+            };
+            try {
+                for (size_t ch = 0; ch < chunk_levels.size(); ch++) {
+                    const int lane = (int)(ch & 1);
+                    join(lane);                   // the lane's previous chunk (two chunks in flight at most)
+                    cur_lane = lane;
+                    Context& lc = lane ? c1 : c;
+                    hipStream_t ls = lane ? s1 : s;
+                    lc.use_device();
+                    InFlight& f = fly[lane];
+                    f.chunk = (int)ch;
+                    f.lane = lane;
+                    auto& cl = chunk_levels[ch];
+                    auto t0 = tick();
+                    for (size_t l = 0; l < cl.size(); l++) {
+                        if (cl[l].empty()) continue;
+                        Split sp = split(cl[l]);
+                        if (!sp.stores.empty()) {     // copy-out enqueued; the rest of the chunk happens in finish()
+                            f.job = stores_enqueue(lc, ls, sp.stores, avail);   // holds the device data alive until the copy ran
+                            f.resume_level = l;
+                            release_inputs(cl[l]);
+                            for (size_t l2 = l + 1; l2 < cl.size(); l2++) release_inputs(cl[l2]);
+                            break;
+                        }
+                        if (!sp.cpu.empty()) run_cpu_nodes(sp.cpu, avail, out_handles);   // export executors
+                        if (!sp.loads.empty()) f.keep.push_back(run_loads(lc, ls, sp.loads, avail));
+                        run_buckets(lc, ls, sp.buckets, sp.bucket_order, avail);
+                        release_inputs(cl[l]);
+                        progress_locked(cl[l].size());
+                    }
+                    if (trace) fprintf(stderr, "[lsa task] chunk %zu lane %d: enqueued in %.2f ms\n", ch, lane, ms_since(t0));
+                    done[lane] = std::async(std::launch::async, finish, &f);
+                }
+                join(0);
+                join(1);
+            } catch (...) {
+                for (int lane = 0; lane < 2; lane++)     // never leave a finisher running on our stack frame
+                    if (done[lane].valid()) {
+                        try {
+                            done[lane].get();
+                        } catch (...) {
+                        }
+                    }
+                cur_lane = 0;
+                throw;
             }
-            finish(fly[0]);
-            finish(fly[1]);
             cur_lane = 0;
         }
         LSA_HIP(hipStreamSynchronize(s));
