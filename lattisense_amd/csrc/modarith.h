@@ -93,7 +93,8 @@ LSA_HD u64 mont_mul_lazy(u64 a, u64 b, u64 q, u64 qinv) {
 LSA_HD u64 shoup_mul_lazy(u64 v, u64 w, u64 ws, u64 q);
 // (measured and dropped: flag-free formulations of the 64-bit compare/select and subtract -- sign masks, a + ~b + 1 through
 // v_lshl_add_u64 -- remove the VCC hazards hipcc's lowering has, but the extra register moves cost more: integer engine
-// 1.63 -> 1.27 TB/s)
+// 1.63 -> 1.27 TB/s; adding t*(2^64-q) instead of subtracting t*q drops a third of the hazard s_nops but 9 more VGPRs cost
+// the plain kernel its fourth workgroup per CU: 1.63 -> 1.53, and 1.62 when forced back to 128 VGPRs)
 LSA_HD u64 sub64(u64 a, u64 b) { return a - b; }
 LSA_HD u64 csub(u64 a, u64 q) { return a >= q ? a - q : a; }
 LSA_HD u64 shoup_mul_lazy(u64 v, u64 w, u64 ws, u64 q) { return sub64(mul_lo64(w, v), mul_lo64(mulhi64(ws, v), q)); }
