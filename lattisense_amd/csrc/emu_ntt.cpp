@@ -5,6 +5,27 @@
 #include "ntt_plan.h"
 #include "tables.h"
 
+template <int NT>
+static void emu_block(const NttPassArgs& a, const NttBlockCtx& bc, u64* lds) {
+    for (int t = 0; t < NT; t++) ntt_phase_load<true, NT>(a, bc, t, lds);
+    int rho[4];
+    const int np = ntt_split(a.mu, rho);
+    if (!a.inverse) {
+        int sig = 0;
+        for (int i = 0; i < np; i++) {
+            for (int t = 0; t < NT; t++) ntt_phase_sub_dyn<NT>(a, bc, t, lds, sig, rho[i]);
+            sig += rho[i];
+        }
+    } else {
+        int sig = a.mu;
+        for (int i = np - 1; i >= 0; i--) {
+            sig -= rho[i];
+            for (int t = 0; t < NT; t++) ntt_phase_sub_dyn<NT>(a, bc, t, lds, sig, rho[i]);
+        }
+    }
+    for (int t = 0; t < NT; t++) ntt_phase_store<true, NT>(a, bc, t, lds);
+}
+
 extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int batch, long long batch_stride, int rows,
                            const unsigned char* mod_of, int period, int inverse, int tau_max, int allow_fp64) {
     lsa::HostTables T;
@@ -35,24 +56,9 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
         for (long long bid = 0; bid < nblocks; bid++) {
             NttBlockCtx bc = ntt_decode_block(a, bid);
             if (bc.mod == LSA_ROW_SKIP) continue;
-            for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_load<true>(a, bc, t, lds.data());
-            int np = (a.mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO, base = a.mu / np, extra = a.mu % np;
-            if (!inverse) {
-                int sig = 0;
-                for (int i = 0; i < np; i++) {
-                    int rho = base + (i < extra ? 1 : 0);
-                    for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_sub_dyn(a, bc, t, lds.data(), sig, rho);
-                    sig += rho;
-                }
-            } else {
-                int sig = a.mu;
-                for (int i = np - 1; i >= 0; i--) {
-                    int rho = base + (i < extra ? 1 : 0);
-                    sig -= rho;
-                    for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_sub_dyn(a, bc, t, lds.data(), sig, rho);
-                }
-            }
-            for (int t = 0; t < LSA_NTT_THREADS; t++) ntt_phase_store<true>(a, bc, t, lds.data());
+            if (a.tau <= 12) emu_block<LSA_NTT_THREADS>(a, bc, lds.data());
+            else if (a.tau == 13) emu_block<512>(a, bc, lds.data());
+            else emu_block<1024>(a, bc, lds.data());
         }
     }
     return 0;

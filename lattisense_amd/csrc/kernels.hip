@@ -23,24 +23,24 @@ static constexpr int TPB = 256;
 #define LSA_STAMP(k) do { } while (0)
 #endif
 
+template <int NT>
 __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
-    const int np = (a.mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO, base = a.mu / np, extra = a.mu % np;
+    int rho[4];
+    const int np = ntt_split(a.mu, rho);
     if (!a.inverse) {
         int sig = 0;
         for (int i = 0; i < np; i++) {
-            const int rho = base + (i < extra ? 1 : 0);
-            ntt_phase_sub_dyn(a, bc, tid, lds, sig, rho);
+            ntt_phase_sub_dyn<NT>(a, bc, tid, lds, sig, rho[i]);
             LSA_STAMP(3 + 2 * i);
             __syncthreads();
             LSA_STAMP(4 + 2 * i);
-            sig += rho;
+            sig += rho[i];
         }
     } else {
         int sig = a.mu;
         for (int i = np - 1; i >= 0; i--) {
-            const int rho = base + (i < extra ? 1 : 0);
-            sig -= rho;
-            ntt_phase_sub_dyn(a, bc, tid, lds, sig, rho);
+            sig -= rho[i];
+            ntt_phase_sub_dyn<NT>(a, bc, tid, lds, sig, rho[i]);
             __syncthreads();
         }
     }
@@ -50,8 +50,11 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
 #ifndef LSA_NTT_WAVES_FUSED
 #define LSA_NTT_WAVES_FUSED LSA_NTT_WAVES
 #endif
-template <bool FZ>
-__global__ __launch_bounds__(LSA_NTT_THREADS, FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
+// NT: workgroup size = tile points / 16.  256 threads (4096-point tiles, 3-4 workgroups per CU) is the two-pass shape;
+// 512 / 1024 threads hold a whole N = 2^13 / 2^14 limb in LDS (69 / 136 KiB) and transform it in ONE pass: half the HBM
+// traffic of the two-pass plan, at one or two workgroups per CU.
+template <bool FZ, int NT>
+__global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
 #if LSA_NTT_TILES_PER_WG == 1
@@ -67,24 +70,24 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT
     }
 #endif
 #if defined(LSA_NTT_DIAG_COMPUTE_ONLY)   // diagnostic build: butterflies on synthetic LDS contents, no global traffic
-    for (int i = tid; i < (1 << a.tau); i += LSA_NTT_THREADS)
+    for (int i = tid; i < (1 << a.tau); i += NT)
         lds[lds_addr(i)] = bc.fp ? d_to_bits((double)(i * 7 + 1)) : (u64)(i * 7 + 1);
     __syncthreads();
-    ntt_butterfly_phases(a, bc, tid, lds);
+    ntt_butterfly_phases<NT>(a, bc, tid, lds);
     if (lds[lds_addr(tid)] == 0x123456789abcull) a.dst[bc.base_dst + tid] = 1;   // keeps the work alive
     return;
 #endif
     LSA_STAMP(0);
-    ntt_phase_load<FZ>(a, bc, tid, lds);
+    ntt_phase_load<FZ, NT>(a, bc, tid, lds);
     LSA_STAMP(1);
     __syncthreads();
     LSA_STAMP(2);
 #if defined(LSA_NTT_DIAG_COPY_ONLY)   // diagnostic build: data movement of the pass structure without butterflies
-    ntt_phase_store<FZ>(a, bc, tid, lds);
+    ntt_phase_store<FZ, NT>(a, bc, tid, lds);
     return;
 #endif
-    ntt_butterfly_phases(a, bc, tid, lds);
-    ntt_phase_store<FZ>(a, bc, tid, lds);
+    ntt_butterfly_phases<NT>(a, bc, tid, lds);
+    ntt_phase_store<FZ, NT>(a, bc, tid, lds);
     LSA_STAMP(7);
 #else
     // software-pipelined walk over consecutive tiles (same limb and tile index, different batch items: same twiddles)
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT
     u64 stage[2 * LSA_NTT_STAGE_PAIRS];
     NttBlockCtx nxt = ntt_decode_block(a, first < a.total_tiles ? first : 0);
     bool have_nxt = first < a.total_tiles && nxt.mod != LSA_ROW_SKIP;
-    if (have_nxt) ntt_phase_fetch(a, nxt, tid, stage);
+    if (have_nxt) ntt_phase_fetch<NT>(a, nxt, tid, stage);
     for (int k = 0; k < LSA_NTT_TILES_PER_WG; k++) {
         const long long bid = first + k;
         if (bid >= a.total_tiles) break;
@@ -103,16 +106,32 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT
             nxt = ntt_decode_block(a, bid + 1);
             have_nxt = nxt.mod != LSA_ROW_SKIP;
         }
-        if (have) ntt_phase_commit(a, bc, tid, lds, stage);
+        if (have) ntt_phase_commit<NT>(a, bc, tid, lds, stage);
         __syncthreads();
-        if (have_nxt) ntt_phase_fetch(a, nxt, tid, stage);   // in flight during the butterflies below
+        if (have_nxt) ntt_phase_fetch<NT>(a, nxt, tid, stage);   // in flight during the butterflies below
         if (have) {
-            ntt_butterfly_phases(a, bc, tid, lds);
-            ntt_phase_store<FZ>(a, bc, tid, lds);
+            ntt_butterfly_phases<NT>(a, bc, tid, lds);
+            ntt_phase_store<FZ, NT>(a, bc, tid, lds);
         }
         __syncthreads();   // LDS is reused by the next tile
     }
 #endif
+}
+
+template <int NT>
+static void ntt_launch_pass(const NttPassArgs& a, bool fused, long long nblocks, size_t lds_bytes, hipStream_t s) {
+    LSA_REQUIRE((1 << a.tau) <= 2 * LSA_NTT_STAGE_PAIRS * NT, "ntt: tile larger than the staging registers");
+    if (lds_bytes > 65536) {   // whole-limb tiles: opt in to more than 64 KiB of dynamic LDS, once per kernel instance
+        static bool raised[2] = {false, false};
+        if (!raised[fused]) {
+            const void* fn = fused ? reinterpret_cast<const void*>(&k_ntt_pass<true, NT>) : reinterpret_cast<const void*>(&k_ntt_pass<false, NT>);
+            LSA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised[fused] = true;
+        }
+    }
+    if (fused) hipLaunchKernelGGL((k_ntt_pass<true, NT>), dim3((unsigned)nblocks), dim3(NT), lds_bytes, s, a);
+    else hipLaunchKernelGGL((k_ntt_pass<false, NT>), dim3((unsigned)nblocks), dim3(NT), lds_bytes, s, a);
+    LSA_HIP(hipGetLastError());
 }
 
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch_stride, int rows, const RowMap& rm,
@@ -169,17 +188,31 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
     for (int r = 0; r < rows; r++) active_rows += rm.mod_of[(rm.row0 + r * rm.row_step) % rm.period] != LSA_ROW_SKIP;
     // Two-pass transforms: run both passes on a chunk of the batch that fits the 256 MiB Infinity Cache before moving
     // on, so the second pass reads what the first just wrote from the memory-side cache instead of HBM.
+    // whole-limb single pass (N = 2^13 / 2^14) where it measured faster: launches that fill the chip at one (2^14) or two
+    // (2^13) workgroups per CU, without fused tails (at 1024 threads their registers spill); at 2^14 only limbs of the
+    // FP64 engine -- the integer engine is bound by its multiplies there, not by traffic (tools/probe_wide.py)
+    bool wide = c.plan_wide.npass < c.plan.npass && c.wide_mode != 0;
+    if (wide && c.wide_mode == 2) {
+        bool all_fp = c.fp64_ntt != 0;
+        for (int r = 0; r < rows && all_fp; r++) {
+            const unsigned char m = rm.mod_of[(rm.row0 + r * rm.row_step) % rm.period];
+            if (m != LSA_ROW_SKIP && (c.T.mods[m].q >> LSA_FP64_MAX_BITS) != 0) all_fp = false;
+        }
+        const long long limbs = (long long)active_rows * batch;
+        wide = !fz && (c.logn == 13 ? limbs >= 1024 : (all_fp && limbs >= 512));
+    }
+    const NttPlan& plan = wide ? c.plan_wide : c.plan;
     int chunk = batch;
-    if (c.plan.npass > 1 && c.ntt_chunk_mib > 0) {
+    if (plan.npass > 1 && c.ntt_chunk_mib > 0) {
         const double per_item = 8.0 * c.n * std::max(active_rows, 1);
         chunk = (int)std::max(1.0, std::min((double)batch, c.ntt_chunk_mib * 1048576.0 / per_item));
     }
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = std::min(chunk, batch - b0);
         a.batch = nb;
-        for (int step = 0; step < c.plan.npass; step++) {
-            const int k = inverse ? c.plan.npass - 1 - step : step;
-            ntt_fill_pass(a, c.plan, c.logn, k, inverse ? 1 : 0);
+        for (int step = 0; step < plan.npass; step++) {
+            const int k = inverse ? plan.npass - 1 - step : step;
+            ntt_fill_pass(a, plan, c.logn, k, inverse ? 1 : 0);
             a.src = (step == 0 ? src + (long long)b0 * src_stride : dst + (long long)b0 * dst_stride);
             a.src_stride = step == 0 ? src_stride : dst_stride;
             a.dst = dst + (long long)b0 * dst_stride;
@@ -187,13 +220,12 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
             a.total_tiles = (long long)nb * rows * (1 << (a.logn - a.tau));
             const long long nblocks = (a.total_tiles + LSA_NTT_TILES_PER_WG - 1) / LSA_NTT_TILES_PER_WG;
             LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
-            LSA_REQUIRE((1 << a.tau) <= 2 * LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS, "ntt: tile larger than the staging registers");
             const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
             // one launch = one pass = 1/npass of the limb transforms it touches (algorithmic 16*N bytes per transform)
-            ProfScope ps(c, PROF_NTT, 16.0 * c.n * active_rows * nb / c.plan.npass, s);
-            if (fz) hipLaunchKernelGGL(k_ntt_pass<true>, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
-            else hipLaunchKernelGGL(k_ntt_pass<false>, dim3((unsigned)nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, a);
-            LSA_HIP(hipGetLastError());
+            ProfScope ps(c, PROF_NTT, 16.0 * c.n * active_rows * nb / plan.npass, s);
+            if (a.tau <= 12) ntt_launch_pass<LSA_NTT_THREADS>(a, fz != nullptr, nblocks, lds_bytes, s);
+            else if (a.tau == 13) ntt_launch_pass<512>(a, fz != nullptr, nblocks, lds_bytes, s);
+            else ntt_launch_pass<1024>(a, fz != nullptr, nblocks, lds_bytes, s);
         }
     }
 }

@@ -70,7 +70,9 @@ struct Context {
     int algo, n, logn, nq, np, nmul, nmod, device;
     u64 t;
     HostTables T;
-    NttPlan plan;
+    NttPlan plan;        // 4096-point tiles: one pass up to N = 2^12, two passes above
+    NttPlan plan_wide;   // N = 2^13 / 2^14 only: the whole limb in one 512 / 1024-thread workgroup, one pass
+    int wide_mode = 2;   // LSA_NTT_WIDE: 0 never, 1 always, unset = per launch (launch_ntt)
     ModDev* d_mods = nullptr;
     u64* d_psi = nullptr;
     u64* d_psiinv = nullptr;

@@ -105,7 +105,7 @@ LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
     c.b = b;
     c.row = row;
     c.fp = 0;
-    if (c.mod != LSA_ROW_SKIP) c.fp = a.allow_fp64 && (a.mods[c.mod].q >> LSA_FP64_MAX_BITS) == 0 && a.mu <= 9;
+    if (c.mod != LSA_ROW_SKIP) c.fp = a.allow_fp64 && (a.mods[c.mod].q >> LSA_FP64_MAX_BITS) == 0;
     return c;
 }
 
@@ -177,7 +177,7 @@ LSA_HD double fp_reduce(double x, double q, double qinv) { return __builtin_fma(
 // LSA_NTT_STAGE_PAIRS pairs) all of a thread's loads are issued before the first one is consumed: a rolled
 // load->convert->ds_write loop serialises one HBM latency per step (measured with the LSA_NTT_DIAG_STAMPS build: 16.3k of
 // a workgroup's 34.6k cycles).
-#define LSA_NTT_STAGE_PAIRS 8   // 16-byte pairs per thread: supports tiles up to 2 * 8 * LSA_NTT_THREADS points
+#define LSA_NTT_STAGE_PAIRS 8   // 16-byte pairs per thread: a workgroup of NT threads stages tiles up to 2 * 8 * NT points
 #ifndef LSA_NTT_HEAD_ROUNDS
 #define LSA_NTT_HEAD_ROUNDS 2   // two-operand prologue: load rounds per tile (1 = all 16 operand pairs in flight at once)
 #endif
@@ -199,7 +199,7 @@ LSA_HD u64 ntt_load_fix(const NttLoadFix& f, u64 v, u64 t) {
     return v;
 }
 // FZ = false compiles the fused prologue out (plain launches: fewer live constants, smaller code)
-template <bool FZ>
+template <bool FZ, int NT>
 LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     const u64* g = a.src + bc.base_src;
     const u64* gl = g;   // last-limb source of the head modes
@@ -220,13 +220,13 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
         f.near = f.ql <= 2 * f.mi.q;
     }
     const NttTileMap tm = ntt_tile_map(a, bc.tile);
-    if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS && !f.add) {
+    if (half == LSA_NTT_STAGE_PAIRS * NT && !f.add) {
         NttLoadFix f1 = f;
         f1.add = false;   // known here: keeps the two-operand arithmetic out of this path's 16 unrolled copies
         u64 st[2 * LSA_NTT_STAGE_PAIRS];
 #pragma unroll
         for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
-            const int x = ntt_tile_index(tm, 2 * (tid + p * LSA_NTT_THREADS));
+            const int x = ntt_tile_index(tm, 2 * (tid + p * NT));
 #if defined(__HIP_DEVICE_COMPILE__)
             const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g + x);
             st[2 * p] = v.x;
@@ -238,20 +238,20 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
         }
 #pragma unroll
         for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
-            const int l = 2 * (tid + p * LSA_NTT_THREADS);
+            const int l = 2 * (tid + p * NT);
             lds[lds_addr(l)] = ntt_load_fix(f1, st[2 * p], st[2 * p]);
             lds[lds_addr(l + 1)] = ntt_load_fix(f1, st[2 * p + 1], st[2 * p + 1]);
         }
         return;
     }
-    if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS) {   // two operands per element: half the pairs per round
+    if (half == LSA_NTT_STAGE_PAIRS * NT) {   // two operands per element: half the pairs per round
         constexpr int CH = LSA_NTT_STAGE_PAIRS / LSA_NTT_HEAD_ROUNDS;
 #pragma unroll 1
         for (int p0 = 0; p0 < LSA_NTT_STAGE_PAIRS; p0 += CH) {
             u64 st[2 * CH], sl[2 * CH];
 #pragma unroll
             for (int p = 0; p < CH; p++) {
-                const int x = ntt_tile_index(tm, 2 * (tid + (p0 + p) * LSA_NTT_THREADS));
+                const int x = ntt_tile_index(tm, 2 * (tid + (p0 + p) * NT));
                 st[2 * p] = g[x];
                 st[2 * p + 1] = g[x + 1];
                 sl[2 * p] = gl[x];
@@ -259,14 +259,14 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
             }
 #pragma unroll
             for (int p = 0; p < CH; p++) {
-                const int l = 2 * (tid + (p0 + p) * LSA_NTT_THREADS);
+                const int l = 2 * (tid + (p0 + p) * NT);
                 lds[lds_addr(l)] = ntt_load_fix(f, st[2 * p], sl[2 * p]);
                 lds[lds_addr(l + 1)] = ntt_load_fix(f, st[2 * p + 1], sl[2 * p + 1]);
             }
         }
         return;
     }
-    for (int i = tid; i < half; i += LSA_NTT_THREADS) {   // partial tiles (small rings)
+    for (int i = tid; i < half; i += NT) {   // partial tiles (small rings)
         const int x = ntt_tile_index(tm, 2 * i);
         lds[lds_addr(2 * i)] = ntt_load_fix(f, g[x], gl[x]);
         lds[lds_addr(2 * i + 1)] = ntt_load_fix(f, g[x + 1], gl[x + 1]);
@@ -275,12 +275,13 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
 
 // The load phase split in two for software pipelining (async-STAGE split): `fetch` only ISSUES the tile's global loads
 // into registers (they stay in flight while the previous tile's butterflies run), `commit` writes them to LDS later.
+template <int NT>
 LSA_HD void ntt_phase_fetch(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* stage /*[2*PAIRS]*/) {
     const u64* g = a.src + bc.base_src;
     const int half = 1 << (a.tau - 1);
 #pragma unroll
     for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
-        const int i = tid + p * LSA_NTT_THREADS;
+        const int i = tid + p * NT;
         if (i < half) {
             const int x = ntt_global_index(a, bc.tile, 2 * i);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -294,11 +295,12 @@ LSA_HD void ntt_phase_fetch(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         }
     }
 }
+template <int NT>
 LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, const u64* stage) {
     const int half = 1 << (a.tau - 1);
 #pragma unroll
     for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
-        const int i = tid + p * LSA_NTT_THREADS;
+        const int i = tid + p * NT;
         if (i < half) {
             u64 v0 = stage[2 * p], v1 = stage[2 * p + 1];
             if (bc.fp) {
@@ -357,7 +359,7 @@ LSA_HD void ntt_store_pair(u64* gp, u64 v0, u64 v1) {
     gp[1] = v1;
 #endif
 }
-template <bool FZ>
+template <bool FZ, int NT>
 LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64* lds) {
     u64* g = a.dst + bc.base_dst;
     const ModDev md = a.mods[bc.mod];
@@ -390,13 +392,13 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         if (f.with_base) pb = a.fz_base + (long long)bc.b * a.fz_base_stride + (((long long)poly * a.fz_base_rpp + limb) << a.logn);
     }
     const NttTileMap tm = ntt_tile_map(a, bc.tile);
-    if (half == LSA_NTT_STAGE_PAIRS * LSA_NTT_THREADS) {
+    if (half == LSA_NTT_STAGE_PAIRS * NT) {
         for (int p0 = 0; p0 < LSA_NTT_STAGE_PAIRS; p0 += LSA_NTT_STORE_CHUNK) {
             u64 v[2 * LSA_NTT_STORE_CHUNK], va[2 * LSA_NTT_STORE_CHUNK], vb[2 * LSA_NTT_STORE_CHUNK];
             int xs[LSA_NTT_STORE_CHUNK];
 #pragma unroll
             for (int p = 0; p < LSA_NTT_STORE_CHUNK; p++) {
-                const int l = 2 * (tid + (p0 + p) * LSA_NTT_THREADS);
+                const int l = 2 * (tid + (p0 + p) * NT);
                 const int x = ntt_tile_index(tm, l);
                 xs[p] = x;
                 v[2 * p] = lds[lds_addr(l)];
@@ -418,7 +420,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         }
         return;
     }
-    for (int i = tid; i < half; i += LSA_NTT_THREADS) {   // partial tiles (small rings)
+    for (int i = tid; i < half; i += NT) {   // partial tiles (small rings)
         const int x = ntt_tile_index(tm, 2 * i);
         const u64 a0 = f.tail ? pa[x] : 0, a1 = f.tail ? pa[x + 1] : 0;
         const u64 b0 = f.with_base ? pb[x] : 0, b1 = f.with_base ? pb[x + 1] : 0;
@@ -429,7 +431,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
 // One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass — integer (Montgomery) engine.
 // LIN: the padded LDS addresses of a group's 2^RHO elements are an arithmetic progression (beta0 == 0 or >= 4), so one
 // add per element replaces the shift/add padding arithmetic.
-template <int RHO, bool LIN>
+template <int RHO, bool LIN, int NT>
 LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const ModDev md = a.mods[bc.mod];
@@ -440,7 +442,7 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
     const bool scale_here = a.inverse && a.apply_scale && a.s_lo + sig0 == 0;
     const u64* sc = a.scale + 4 * bc.mod;
     const u64 sc0 = scale_here ? sc[0] : 0, sc0s = scale_here ? sc[1] : 0, sc1 = scale_here ? sc[2] : 0, sc1s = scale_here ? sc[3] : 0;
-    for (int gid = tid; gid < ngroups; gid += LSA_NTT_THREADS) {
+    for (int gid = tid; gid < ngroups; gid += NT) {
         int lbase = ((gid >> beta0) << (beta0 + RHO)) | (gid & ((1 << beta0) - 1));
         const int ad0 = lds_addr(lbase), adst = !LIN ? 0 : beta0 ? (1 << beta0) + (1 << (beta0 - 4)) : 1;
         u64 v[E];
@@ -499,7 +501,7 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
 }
 
 // The same sub-pass on the FP64 engine: LDS holds integer-valued doubles.
-template <int RHO, bool LIN>
+template <int RHO, bool LIN, int NT>
 LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const double q = (double)a.mods[bc.mod].q, qinv = 1.0 / q;
@@ -508,7 +510,7 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
     const int ngroups = 1 << (a.tau - RHO);
     const bool scale_here = a.inverse && a.apply_scale && a.s_lo + sig0 == 0;
     const double sc0 = scale_here ? a.scaled[2 * bc.mod] : 0.0, sc1 = scale_here ? a.scaled[2 * bc.mod + 1] : 0.0;
-    for (int gid = tid; gid < ngroups; gid += LSA_NTT_THREADS) {
+    for (int gid = tid; gid < ngroups; gid += NT) {
         int lbase = ((gid >> beta0) << (beta0 + RHO)) | (gid & ((1 << beta0) - 1));
         const int ad0 = lds_addr(lbase), adst = !LIN ? 0 : beta0 ? (1 << beta0) + (1 << (beta0 - 4)) : 1;
         double v[E];
@@ -536,6 +538,10 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
                         v[e + half] = U - T;
                     }
                 }
+            }
+            if (a.mu > 9) {   // longer (single-pass) transforms: back to |.| <= q/2+1 after every sub-pass (< 4q + 4.4q inside one)
+#pragma unroll
+                for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], q, qinv);
             }
         } else {
 #pragma unroll
@@ -569,25 +575,32 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
     }
 }
 
-// sub-pass plan: split mu stages into ceil(mu/4) nearly equal radix groups (each <= 4)
-LSA_HD int ntt_plan(int mu, int* rho /*[4]*/) {
-    int n = (mu + 3) / 4;
-    int base = mu / n, extra = mu % n;
+// sub-pass plan: mu stages as ceil(mu/MAX_RHO) radix groups in local stage order.  Up to 12 stages: nearly equal groups.
+// Longer (single-pass N = 2^13 / 2^14) transforms: full radix-16 groups with the remainder second to last, which keeps
+// every group's lowest active bit at 0 or >= 4 (the conflict-free linear LDS addressing of ntt_phase_sub).
+LSA_HD int ntt_split(int mu, int* rho /*[4]*/) {
+    const int n = (mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO;
+    if (mu > 12 && LSA_NTT_MAX_RHO == 4) {
+        for (int i = 0; i < n; i++) rho[i] = 4;
+        rho[n - 2] = mu - 4 * (n - 1);
+        return n;
+    }
+    const int base = mu / n, extra = mu % n;
     for (int i = 0; i < n; i++) rho[i] = base + (i < extra ? 1 : 0);
     return n;
 }
 
-template <bool LIN>
+template <bool LIN, int NT>
 LSA_HD void ntt_phase_sub_sel(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
     if (bc.fp) {
         switch (rho) {
-            case 1: ntt_phase_sub_fp<1, LIN>(a, bc, tid, lds, sig0); break;
-            case 2: ntt_phase_sub_fp<2, LIN>(a, bc, tid, lds, sig0); break;
+            case 1: ntt_phase_sub_fp<1, LIN, NT>(a, bc, tid, lds, sig0); break;
+            case 2: ntt_phase_sub_fp<2, LIN, NT>(a, bc, tid, lds, sig0); break;
 #if LSA_NTT_MAX_RHO >= 4
-            case 3: ntt_phase_sub_fp<3, LIN>(a, bc, tid, lds, sig0); break;
-            default: ntt_phase_sub_fp<4, LIN>(a, bc, tid, lds, sig0); break;
+            case 3: ntt_phase_sub_fp<3, LIN, NT>(a, bc, tid, lds, sig0); break;
+            default: ntt_phase_sub_fp<4, LIN, NT>(a, bc, tid, lds, sig0); break;
 #elif LSA_NTT_MAX_RHO == 3
-            default: ntt_phase_sub_fp<3, LIN>(a, bc, tid, lds, sig0); break;
+            default: ntt_phase_sub_fp<3, LIN, NT>(a, bc, tid, lds, sig0); break;
 #else
             default: break;
 #endif
@@ -595,23 +608,24 @@ LSA_HD void ntt_phase_sub_sel(const NttPassArgs& a, const NttBlockCtx& bc, int t
         return;
     }
     switch (rho) {
-        case 1: ntt_phase_sub<1, LIN>(a, bc, tid, lds, sig0); break;
-        case 2: ntt_phase_sub<2, LIN>(a, bc, tid, lds, sig0); break;
+        case 1: ntt_phase_sub<1, LIN, NT>(a, bc, tid, lds, sig0); break;
+        case 2: ntt_phase_sub<2, LIN, NT>(a, bc, tid, lds, sig0); break;
 #if LSA_NTT_MAX_RHO >= 4
-        case 3: ntt_phase_sub<3, LIN>(a, bc, tid, lds, sig0); break;
-        default: ntt_phase_sub<4, LIN>(a, bc, tid, lds, sig0); break;
+        case 3: ntt_phase_sub<3, LIN, NT>(a, bc, tid, lds, sig0); break;
+        default: ntt_phase_sub<4, LIN, NT>(a, bc, tid, lds, sig0); break;
 #elif LSA_NTT_MAX_RHO == 3
-        default: ntt_phase_sub<3, LIN>(a, bc, tid, lds, sig0); break;
+        default: ntt_phase_sub<3, LIN, NT>(a, bc, tid, lds, sig0); break;
 #else
         default: break;
 #endif
     }
 }
 
+template <int NT>
 LSA_HD void ntt_phase_sub_dyn(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
     const int beta0 = a.lambda + a.mu - sig0 - rho;
     if (beta0 == 0 || beta0 >= 4)
-        ntt_phase_sub_sel<true>(a, bc, tid, lds, sig0, rho);
+        ntt_phase_sub_sel<true, NT>(a, bc, tid, lds, sig0, rho);
     else
-        ntt_phase_sub_sel<false>(a, bc, tid, lds, sig0, rho);
+        ntt_phase_sub_sel<false, NT>(a, bc, tid, lds, sig0, rho);
 }

@@ -53,14 +53,14 @@ def _check(emu, logn, tau, mods, fp64):
     assert np.array_equal(got, data)
 
 
-# (logn, tau_max): single pass, two passes with several (mu_a, mu_b) splits incl. odd logn
-@pytest.mark.parametrize("logn,tau", [(8, 12), (10, 12), (12, 12), (13, 12), (14, 12), (11, 8), (13, 10), (15, 12)])
+# (logn, tau_max): single pass (incl. the whole-limb 2^13 / 2^14 shapes), two passes with several (mu_a, mu_b) splits incl. odd logn
+@pytest.mark.parametrize("logn,tau", [(8, 12), (10, 12), (12, 12), (13, 12), (14, 12), (11, 8), (13, 10), (15, 12), (13, 13), (14, 14)])
 def test_integer_engine_matches_oracle(emu, logn, tau):
     B = params.CKKS_BOOTSTRAP_65536
     _check(emu, logn, tau, B["q"][:2] + B["p"][:1], fp64=0)   # 60-, 40-, 61-bit
 
 
-@pytest.mark.parametrize("logn,tau", [(9, 12), (12, 12), (13, 12), (14, 12), (15, 12), (13, 10)])
+@pytest.mark.parametrize("logn,tau", [(9, 12), (12, 12), (13, 12), (14, 12), (15, 12), (13, 10), (13, 13), (14, 14)])
 def test_fp64_engine_matches_oracle(emu, logn, tau):
     # 46/45-bit (largest primes the FP64 engine accepts in the default chains), 40- and 39-bit, plus a 60-bit limb that
     # must keep using the integer engine inside the same launch

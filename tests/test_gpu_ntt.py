@@ -9,9 +9,11 @@ from tests.gpu_util import need_gpu, rand_ct
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("logn", [10, 12, 13, 14, 15, 16])
-def test_ntt_roundtrip_and_parity(logn):
+@pytest.mark.parametrize("logn,wide", [(10, 0), (12, 0), (13, 0), (14, 0), (15, 0), (16, 0), (13, 1), (14, 1)])
+def test_ntt_roundtrip_and_parity(logn, wide, monkeypatch):
+    """wide = 1: the whole-limb single-pass plan of N = 2^13 / 2^14 (512 / 1024-thread workgroups, LSA_NTT_WIDE=1)."""
     need_gpu()
+    monkeypatch.setenv("LSA_NTT_WIDE", str(wide))
     from lattisense_amd.device import DeviceContext, ALGO_CKKS
     from oracle.pyoracle import Oracle
     n = 1 << logn
