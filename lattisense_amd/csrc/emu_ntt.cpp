@@ -28,6 +28,8 @@ static void emu_block(const NttPassArgs& a, const NttBlockCtx& bc, u64* lds) {
 
 extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int batch, long long batch_stride, int rows,
                            const unsigned char* mod_of, int period, int inverse, int tau_max, int allow_fp64) {
+    const int row_inner = allow_fp64 >> 1;   // bit 1: the (tile, row, batch) workgroup order
+    allow_fp64 &= 1;
     lsa::HostTables T;
     T.build(n, std::vector<u64>(moduli, moduli + nmod));
     NttPlan plan = make_ntt_plan(T.logn, tau_max);
@@ -47,6 +49,7 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
     a.period = period;
     a.row0 = 0;
     a.row_step = 1;
+    a.row_inner = row_inner;
     for (int i = 0; i < period; i++) a.mod_of[i] = mod_of[i];
     for (int step = 0; step < plan.npass; step++) {
         int k = inverse ? plan.npass - 1 - step : step;

@@ -202,6 +202,17 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         wide = !fz && (c.logn == 13 ? limbs >= 1024 : (all_fp && limbs >= 512));
     }
     const NttPlan& plan = wide ? c.plan_wide : c.plan;
+    {   // launches that mix both butterfly engines interleave their limbs (+1.4 % hmult / +2.2 % rotate NTT rate, profiles/r01/ab_row_inner.log)
+        bool any_fp = false, any_int = false;
+        for (int r = 0; r < rows; r++) {
+            const unsigned char m = rm.mod_of[(rm.row0 + r * rm.row_step) % rm.period];
+            if (m == LSA_ROW_SKIP) continue;
+            const bool fp = c.fp64_ntt && (c.T.mods[m].q >> LSA_FP64_MAX_BITS) == 0;
+            any_fp |= fp;
+            any_int |= !fp;
+        }
+        a.row_inner = any_fp && any_int;
+    }
     int chunk = batch;
     if (plan.npass > 1 && c.ntt_chunk_mib > 0) {
         const double per_item = 8.0 * c.n * std::max(active_rows, 1);

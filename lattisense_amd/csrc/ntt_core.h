@@ -59,6 +59,7 @@ struct NttPassArgs {
     int allow_fp64;       // 0 forces the integer engine for every limb
     int period;           // row r uses modulus mod_of[r % period]
     int row0, row_step;   // the launch's i-th row is row r = row0 + i * row_step of the batch item
+    int row_inner;        // workgroup order: 0 = (row, tile, batch), 1 = (tile, row, batch), batch fastest in both
     // ---- fused element-wise tails (rows of the transformed buffer are [poly][fz_limbs]):
     // epilogue of the LAST pass of a forward transform, replaces the plain store of the transformed value v:
     //   fz_epi = 1:  out[poly][limb] = (fz_a[poly][limb] - v) * fz_k[limb]  (+ fz_base[poly][limb] if poly < fz_base_polys)
@@ -97,8 +98,16 @@ LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
     int tiles = 1 << (a.logn - a.tau);
     int b = (int)(bid % a.batch);
     long long rt = bid / a.batch;
-    c.tile = (int)(rt % tiles);
-    int row = a.row0 + (int)(rt / tiles) * a.row_step;
+    int row;
+    if (a.row_inner) {
+        // rows in the middle: consecutive batch-sized runs of workgroups walk over the launch's limbs at one tile position,
+        // so the workgroups resident on a CU mix integer-engine (multiply-bound) and FP64-engine (traffic-bound) limbs
+        c.tile = (int)(rt / a.rows);
+        row = a.row0 + (int)(rt % a.rows) * a.row_step;
+    } else {
+        c.tile = (int)(rt % tiles);
+        row = a.row0 + (int)(rt / tiles) * a.row_step;
+    }
     c.base_src = (long long)b * a.src_stride + ((long long)row << a.logn);
     c.base_dst = (long long)b * a.dst_stride + ((long long)row << a.logn);
     c.mod = a.mod_of[row % a.period];

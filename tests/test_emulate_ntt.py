@@ -70,3 +70,4 @@ def test_fp64_engine_matches_oracle(emu, logn, tau):
     assert max(m.bit_length() for m in mods[:4]) <= 46
     _check(emu, logn, tau, mods, fp64=1)
     _check(emu, logn, tau, mods, fp64=0)
+    _check(emu, logn, tau, mods, fp64=3)   # the interleaved workgroup order of mixed-engine launches
