@@ -48,6 +48,10 @@ for case in range(cases):
         t = 0
     nq = len(q)
     o = Oracle(n, q, p, t)
+    # the NTT plan switch is read when the context is built: unset = per launch, 1 = whole-limb single pass at 2^13 / 2^14
+    os.environ.pop("LSA_NTT_WIDE", None)
+    if case % 2:
+        os.environ["LSA_NTT_WIDE"] = "1"
     ctx = DeviceContext(ALGO_BFV if bfv else ALGO_CKKS, n, q, p, t)
     klvl = nq - 1
     lvl = int(rng.integers(1, nq))          # >= 1 (rescale needs a level)
