@@ -9,6 +9,7 @@
 //   * a limb of N = 2^logn points is transformed in one or two PASSES; a pass covers `mu` consecutive radix-2 stages
 //     [s_lo, s_lo+mu) on a TILE of 2^tau points staged through LDS (<= 34 KiB so 4 workgroups share a CU's 160 KiB
 //     and their HBM loads / butterflies / stores overlap);
+//     N = 2^13 / 2^14 also have a whole-limb plan (one pass, 512 / 1024 threads, 69 / 136 KiB of LDS), picked per launch;
 //   * inside a pass every thread owns radix-2^rho groups (rho <= 4): 16 points live in VGPRs for 4 stages, so a point
 //     crosses LDS once per 4 stages instead of once per stage;
 //   * all global accesses are 16 B/lane and contiguous per wave (pass A gathers >=128 B column segments);
@@ -18,7 +19,8 @@
 //     therefore stays in L1/L2 (twiddles are excluded from the algorithmic byte count for exactly that reason).
 //
 // Two butterfly engines, chosen per workgroup from the limb's modulus (results are the same canonical residues):
-//   INT  (any q < 2^61): Montgomery radix 2^64 on v_mad_u64_u32 chains, Harvey-lazy values in [0,4q);
+//   INT  (any q < 2^61): Shoup/Harvey butterflies on v_mad_u64_u32 chains -- every twiddle w is stored with its quotient
+//         w' = floor(w*2^64/q), w*v mod q = w*v - mulhi(w', v)*q in [0,2q) -- lazy values in [0,4q);
 //   FP64 (q < 2^47, i.e. most CKKS chain primes): every butterfly is 6 double-precision ops
 //         h = v*w ; l = fma(v,w,-h) ; c = rndne(h/q) ; d = fma(-c,q,h) ; t = d + l     (all exact, |t| < 1.1 q)
 //     — the kernel is VALU-issue bound on the quarter-rate integer multiplier (rocprof: profiles/ntt_r1a_*), and
@@ -437,7 +439,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     }
 }
 
-// One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass — integer (Montgomery) engine.
+// One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass — integer (Shoup) engine.
 // LIN: the padded LDS addresses of a group's 2^RHO elements are an arithmetic progression (beta0 == 0 or >= 4), so one
 // add per element replaces the shift/add padding arithmetic.
 template <int RHO, bool LIN, int NT>

@@ -1,5 +1,5 @@
 """Replays the HIP NTT kernel's phase functions on the CPU (one simulated thread at a time) and checks them
-bit-exactly against the oracle, for both butterfly engines (integer Montgomery; exact FP64-FMA for q < 2^47).
+bit-exactly against the oracle, for both butterfly engines (integer Shoup; exact FP64-FMA for q < 2^47).
 This validates the kernel's tile/sub-pass/twiddle indexing and the FP64 exactness argument without a GPU;
 the real kernel is checked on the GPU in tests/test_gpu_*.py."""
 import ctypes
