@@ -31,7 +31,9 @@ Context::Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_
 #ifndef LSA_NTT_TAU
 #define LSA_NTT_TAU 12   // log2 of the LDS tile (points per workgroup pass)
 #endif
-    plan = make_ntt_plan(logn, LSA_NTT_TAU);
+    int mu_a = 0;
+    if (const char* e = std::getenv("LSA_NTT_MU_A")) mu_a = std::atoi(e);   // A/B: stages of the first pass
+    plan = make_ntt_plan(logn, LSA_NTT_TAU, mu_a);
     // N = 2^13 / 2^14: the whole limb also fits one workgroup's LDS (69 / 136 KiB) and can be transformed in a single pass
     // of 512 / 1024 threads: half the HBM traffic, but one or two workgroups per CU and R limbs fill only R CUs --
     // launch_ntt picks per launch; LSA_NTT_WIDE=0 / 1 forces never / always.

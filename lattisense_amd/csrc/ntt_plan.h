@@ -7,7 +7,7 @@ struct NttPlan { int npass; NttPassShape pass[2]; };
 
 // logn <= tau_max: one pass with the whole limb in LDS.  Otherwise two passes:
 // A = stages [0, floor(logn/2)) on strided columns, B = the remaining stages on contiguous chunks.
-inline NttPlan make_ntt_plan(int logn, int tau_max = 12) {
+inline NttPlan make_ntt_plan(int logn, int tau_max = 12, int mu_a_override = 0) {
     NttPlan p;
     if (logn <= tau_max) {
         p.npass = 1;
@@ -16,6 +16,8 @@ inline NttPlan make_ntt_plan(int logn, int tau_max = 12) {
         // pass A keeps >= 16 columns (128-byte segments) per tile: mu_a <= tau - 4
         int mu_a = logn / 2;
         if (mu_a > tau_max - 4) mu_a = tau_max - 4;
+        // fewer first-pass stages = longer contiguous column segments (2^(tau - mu_a) elements) per tile row
+        if (mu_a_override > 0 && mu_a_override <= tau_max - 4 && logn - mu_a_override <= tau_max) mu_a = mu_a_override;
         int mu_b = logn - mu_a;
         p.npass = 2;
         p.pass[0] = {0, mu_a, tau_max - mu_a, tau_max};
