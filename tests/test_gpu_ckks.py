@@ -21,6 +21,18 @@ def _setup(n, nq, seed=3):
 
 @pytest.mark.parametrize("n,lvl", [(1024, 4), (4096, 2), (8192, 5)])
 def test_mult_relin_rescale_bit_exact_and_decrypts(n, lvl):
+    _mult_relin_rescale_case(n, lvl)
+
+
+def test_fused_modup_first_pass_bit_exact(monkeypatch):
+    """LSA_FUSE_MODUP=1: the key switch's ModUp conversion runs inside the first NTT pass of the extension
+    (k_modup_ntt, N >= 2^13; experimental, off by default) -- same residues as the oracle."""
+    monkeypatch.setenv("LSA_FUSE_MODUP", "1")
+    _mult_relin_rescale_case(8192, 5)
+    _mult_relin_rescale_case(16384, 3)
+
+
+def _mult_relin_rescale_case(n, lvl):
     need_gpu()
     from oracle.client import Client, mean_precision_bits
     ctx, o, q, p = _setup(n, 6)
