@@ -660,11 +660,12 @@ void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows
 }
 
 // ------------------------------------------------------------------------------------------------ ModUp + first NTT pass
-// One workgroup = one first-pass tile (2048 points: 128 strided rows x 16 columns) of one batch item and one GROUP of the
-// digit's target limbs.  The tile's source coefficients are loaded once, y_i and the float quotient v computed once (as in
-// k_baseconv, 8 points per thread: 64 VGPRs for 4 sources), then target by target: convert -> LDS -> the first-pass
-// butterflies -> store in the layout the second pass reads.  The converted limb is never written in the coefficient
-// domain: per digit ns*g + nd + 2*nd limb streams instead of (ns + nd) + 2*nd + 2*nd.
+// One workgroup = one first-pass tile (1024 points: 64 strided rows x 16 columns, 6 stages; or 2048 points, 7 stages) of
+// one batch item and one GROUP of the digit's target limbs.  The tile's source coefficients are loaded once, y_i and the
+// float quotient v computed once (as in k_baseconv; 4 points per thread = 32 VGPRs of y for 4 sources), then target by
+// target: convert -> LDS -> the first-pass butterflies -> store in the layout the second pass reads.  The converted limb
+// is never written in the coefficient domain: per digit ns*g + nd + 2*nd limb streams instead of (ns + nd) + 2*nd + 2*nd.
+// EXPERIMENTAL (LSA_FUSE_MODUP=1): bit-exact, break-even against the two kernels it replaces.
 struct ModUpNttArgs {
     NttPassArgs a;   // first-pass shape, dst / dst_stride = extension buffer, mods, twiddles (rows / mod_of unused)
     const BaseConvConsts* k;
@@ -675,12 +676,13 @@ struct ModUpNttArgs {
 };
 
 #ifndef LSA_MODUP_WAVES
-#define LSA_MODUP_WAVES 2   // workgroups per CU the register allocator must allow (y and the butterfly state live together)
+#define LSA_MODUP_WAVES 2   // workgroups per CU the register allocator must allow for 2048-point tiles (y and the butterfly state
+                            // live together); 1024-point tiles: 4 up to 4 sources (14 spilled VGPRs, still +1.5 %), 3 with 5
 #endif
-template <int NS>
-__global__ __launch_bounds__(LSA_NTT_THREADS, LSA_MODUP_WAVES) void k_modup_ntt(ModUpNttArgs g) {
+template <int NS, int PAIRS>   // PAIRS 16-byte pairs per thread: 2048-point (4) or 1024-point (2) first-pass tiles
+__global__ __launch_bounds__(LSA_NTT_THREADS, PAIRS == 4 ? LSA_MODUP_WAVES : NS <= 4 ? LSA_MODUP_WAVES + 2 : LSA_MODUP_WAVES + 1) void k_modup_ntt(ModUpNttArgs g) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    constexpr int NT = LSA_NTT_THREADS, PAIRS = 4;   // 2048-point tile: 4 pairs per thread
+    constexpr int NT = LSA_NTT_THREADS;
     const NttPassArgs& a = g.a;
     const BaseConvConsts& K = *g.k;
     const int tid = threadIdx.x;
@@ -761,21 +763,22 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, LSA_MODUP_WAVES) void k_modup_ntt(
             lds[lds_addr(lidx)] = bc.fp ? d_to_bits(u52_to_double(r)) : r;
         }
         __syncthreads();
-        // the pass's 7 stages as radix-8 / 4 / 4 sub-passes, instantiated directly: every thread owns a group in each
-        // (a radix-16 sub-pass of a 2048-point tile would idle half the workgroup) and the radix-16 register footprint
-        // stays out of this kernel, whose y values live across the butterflies
+        // the pass's stages as radix-8 / 4 / 4 (2048 points, 7 stages) or 4 / 4 / 4 (1024 points, 6 stages) sub-passes,
+        // instantiated directly: every thread owns a group in each (a radix-16 sub-pass would idle part of the workgroup)
+        // and the radix-16 register footprint stays out of this kernel, whose y values live across the butterflies
+        constexpr int R0 = PAIRS == 4 ? 3 : 2;
         if (bc.fp) {
-            ntt_phase_sub_fp<3, true, NT>(a, bc, tid, lds, 0);
+            ntt_phase_sub_fp<R0, true, NT>(a, bc, tid, lds, 0);
             __syncthreads();
-            ntt_phase_sub_fp<2, true, NT>(a, bc, tid, lds, 3);
+            ntt_phase_sub_fp<2, true, NT>(a, bc, tid, lds, R0);
             __syncthreads();
-            ntt_phase_sub_fp<2, true, NT>(a, bc, tid, lds, 5);
+            ntt_phase_sub_fp<2, true, NT>(a, bc, tid, lds, R0 + 2);
         } else {
-            ntt_phase_sub<3, true, NT>(a, bc, tid, lds, 0);
+            ntt_phase_sub<R0, true, NT>(a, bc, tid, lds, 0);
             __syncthreads();
-            ntt_phase_sub<2, true, NT>(a, bc, tid, lds, 3);
+            ntt_phase_sub<2, true, NT>(a, bc, tid, lds, R0);
             __syncthreads();
-            ntt_phase_sub<2, true, NT>(a, bc, tid, lds, 5);
+            ntt_phase_sub<2, true, NT>(a, bc, tid, lds, R0 + 2);
         }
         __syncthreads();
         ntt_phase_store<false, NT>(a, bc, tid, lds);
@@ -785,7 +788,8 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, LSA_MODUP_WAVES) void k_modup_ntt(
 
 template <int NS>
 static void launch_modup_ntt_ns(const ModUpNttArgs& g, unsigned nblocks, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL((k_modup_ntt<NS>), dim3(nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, g);
+    if (g.a.tau == 11) hipLaunchKernelGGL((k_modup_ntt<NS, 4>), dim3(nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, g);
+    else hipLaunchKernelGGL((k_modup_ntt<NS, 2>), dim3(nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, g);
 }
 
 // the first pass of `plan` (a two-pass plan whose first tile is 2048 points) over the conversion of one digit; the caller
@@ -794,8 +798,9 @@ void launch_modup_ntt(Context& c, const BaseConvPlan* k, const BaseConvRows& row
                       long long sext, int batch, const NttPlan& plan, hipStream_t s) {
     if (batch <= 0) return;
     LSA_REQUIRE(k->ns >= 1 && k->ns <= 5, "fused ModUp: at most 5 source limbs");
-    LSA_REQUIRE(plan.npass == 2 && plan.pass[0].tau == 11 && plan.pass[0].mu == 7 && plan.pass[0].lambda == 4 && LSA_NTT_THREADS == 256,
-                "fused ModUp: needs the 2048-point, 7-stage first pass");
+    const NttPassShape& p0 = plan.pass[0];
+    LSA_REQUIRE(plan.npass == 2 && p0.lambda == 4 && ((p0.tau == 11 && p0.mu == 7) || (p0.tau == 10 && p0.mu == 6)) && LSA_NTT_THREADS == 256,
+                "fused ModUp: needs a 2048-point / 7-stage or 1024-point / 6-stage first pass");
     ModUpNttArgs g{};
     NttPassArgs& a = g.a;
     a.batch = batch;

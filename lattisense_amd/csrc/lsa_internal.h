@@ -85,7 +85,7 @@ struct Context {
     int fuse_tails = 1;             // ModDown / rescale element-wise tails fused into the NTT load/store phases
     int fuse_modup = 0;             // ModUp conversion fused into the first NTT pass of the extension (LSA_FUSE_MODUP=1)
     int modup_tgt = 0;              // targets per workgroup of the fused kernel (LSA_MODUP_TGT, default 7)
-    NttPlan plan_modup;             // its two-pass plan: 2048-point first-pass tiles (7 stages), the rest in the second
+    NttPlan plan_modup;             // its two-pass plan: 1024-point first-pass tiles (6 stages; LSA_MODUP_TILE=2048: 7), the rest in the second
     int dual_stream = 0;            // 1: overlap alternate tiles of an operator on an auxiliary stream (+5% throughput,
                                     // but per-kernel timings then include the co-running kernel; off for clean accounting)
     hipStream_t aux_stream = nullptr;

@@ -591,7 +591,7 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 // every group's lowest active bit at 0 or >= 4 (the conflict-free linear LDS addressing of ntt_phase_sub).
 LSA_HD int ntt_split(int mu, int* rho /*[4]*/) {
     const int n = (mu + LSA_NTT_MAX_RHO - 1) / LSA_NTT_MAX_RHO;
-    if (mu > 12 && LSA_NTT_MAX_RHO == 4) {
+    if ((mu > 12 || mu == 10) && LSA_NTT_MAX_RHO == 4) {   // 10 = 4 + 2 + 4 (4 + 3 + 3 would put a group's lowest bit at 3)
         for (int i = 0; i < n; i++) rho[i] = 4;
         rho[n - 2] = mu - 4 * (n - 1);
         return n;

@@ -60,7 +60,7 @@ def test_integer_engine_matches_oracle(emu, logn, tau):
     _check(emu, logn, tau, B["q"][:2] + B["p"][:1], fp64=0)   # 60-, 40-, 61-bit
 
 
-@pytest.mark.parametrize("logn,tau", [(9, 12), (12, 12), (13, 12), (14, 12), (15, 12), (13, 10), (13, 13), (14, 14)])
+@pytest.mark.parametrize("logn,tau", [(9, 12), (10, 12), (12, 12), (13, 12), (14, 12), (15, 12), (13, 10), (13, 13), (14, 14)])
 def test_fp64_engine_matches_oracle(emu, logn, tau):
     # 46/45-bit (largest primes the FP64 engine accepts in the default chains), 40- and 39-bit, plus a 60-bit limb that
     # must keep using the integer engine inside the same launch
