@@ -1368,7 +1368,32 @@ __global__ __launch_bounds__(TPB) void k_probe_shoup(u64* buf, size_t n, int ite
     buf[4 * i + 2] = c;
     buf[4 * i + 3] = d;
 }
+// the same chains on the FP64 engine's exact modular product (6 double operations: mul, fma, mul, rndne, fma, add)
+__global__ __launch_bounds__(TPB) void k_probe_fp(u64* buf, size_t n, int iters) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i * 4 + 3 >= n) return;
+    const double q = 70368744161281.0, qinv = 1.0 / q;   // a 46-bit modulus; values irrelevant for timing
+    double a = (double)(buf[4 * i] & 0xFFFFFFFFFFull), b = (double)(buf[4 * i + 1] & 0xFFFFFFFFFFull);
+    double c = (double)(buf[4 * i + 2] & 0xFFFFFFFFFFull), d = (double)(buf[4 * i + 3] & 0xFFFFFFFFFFull);
+    const double w = a + 1.0;
+    for (int it = 0; it < iters; it++) {
+        a = fp_modmul(a, w + it, q, qinv);
+        b = fp_modmul(b, w + it, q, qinv);
+        c = fp_modmul(c, w + it, q, qinv);
+        d = fp_modmul(d, w + it, q, qinv);
+    }
+    buf[4 * i] = (u64)(long long)a;
+    buf[4 * i + 1] = (u64)(long long)b;
+    buf[4 * i + 2] = (u64)(long long)c;
+    buf[4 * i + 3] = (u64)(long long)d;
+}
 void launch_probe_mulhi(u64* buf, size_t n, int iters, hipStream_t s) {
+    if (iters >= (1 << 20)) {   // offset by 2^20: the FP64 variant
+        const size_t threads = n / 4;
+        hipLaunchKernelGGL(k_probe_fp, dim3((unsigned)((threads + TPB - 1) / TPB)), dim3(TPB), 0, s, buf, n, iters - (1 << 20));
+        LSA_HIP(hipGetLastError());
+        return;
+    }
     if (iters < 0) {   // negative: the Shoup variant
         const size_t threads = n / 4;
         hipLaunchKernelGGL(k_probe_shoup, dim3((unsigned)((threads + TPB - 1) / TPB)), dim3(TPB), 0, s, buf, n, -iters);
