@@ -23,11 +23,13 @@
 //         w' = floor(w*2^64/q), w*v mod q = w*v - mulhi(w', v)*q in [0,2q) -- lazy values in [0,4q);
 //   FP64 (q < 2^47, i.e. most CKKS chain primes): every butterfly is 6 double-precision ops
 //         h = v*w ; l = fma(v,w,-h) ; c = rndne(h/q) ; d = fma(-c,q,h) ; t = d + l     (all exact, |t| < 1.1 q)
-//     — the kernel is VALU-issue bound on the quarter-rate integer multiplier (rocprof: profiles/ntt_r1a_*), and
-//     v_fma_f64 issues at 4x the rate of v_mad_u64_u32.  Exactness: operands are integers of magnitude < 2^51,
+//     — ~9 VALU issue slots per butterfly against ~30 plus VCC hazards on the integer engine (both the 32-bit integer
+//     multiplies and the double operations issue at full rate on gfx950, tools/probe_mul.py: the integer engine is bound by
+//     its instruction count -- carries, compare/select chains, register-pair moves -- not by the multiplier).  Exactness: operands are integers of magnitude < 2^51,
 //     h+l is the exact product (FMA error-free transformation), |h/q| < 2^51 keeps c within 1 of the true quotient, so
 //     d and d+l are integers below 2^53 and therefore exact.  A forward pass of <= 9 stages needs no reduction
-//     (growth <= 1.1q per stage); the inverse reduces once per sub-pass (sums double per stage).
+//     (growth <= 1.1q per stage; longer single-pass transforms reduce after every sub-pass); the inverse reduces once per
+//     sub-pass (sums double per stage).
 #pragma once
 #include "modarith.h"
 
