@@ -749,6 +749,15 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, PAIRS == 4 ? LSA_MODUP_WAVES : NS 
         bc.b = b;
         bc.row = g.rows.dst_row[j];
         bc.fp = a.allow_fp64 && (m.q >> LSA_FP64_MAX_BITS) == 0;
+        // this target's first-pass twiddles (indices below 2^mu: 1 KiB) go through LDS: fetched here, under the conversion,
+        // instead of once per sub-pass from global memory with nothing to hide the latency behind
+        u64* tw_l = lds + lds_words(a.tau);
+        bc.tw_l = tw_l;
+        ulonglong2 twp = {0, 0};
+        if (tid < (1 << a.mu)) {
+            if (bc.fp) twp.x = d_to_bits(a.twd[((long long)mod << a.logn) + tid]);
+            else twp = ld2(a.tw + (((long long)mod << a.logn) << 1) + 2 * tid);
+        }
         u64 w[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) w[i] = K.shat_m[j][i];
@@ -762,23 +771,30 @@ __global__ __launch_bounds__(LSA_NTT_THREADS, PAIRS == 4 ? LSA_MODUP_WAVES : NS 
             const int lidx = 2 * (tid + (e >> 1) * NT) + (e & 1);
             lds[lds_addr(lidx)] = bc.fp ? d_to_bits(u52_to_double(r)) : r;
         }
+        if (tid < (1 << a.mu)) {
+            if (bc.fp) tw_l[tid] = twp.x;
+            else {
+                tw_l[2 * tid] = twp.x;
+                tw_l[2 * tid + 1] = twp.y;
+            }
+        }
         __syncthreads();
         // the pass's stages as radix-8 / 4 / 4 (2048 points, 7 stages) or 4 / 4 / 4 (1024 points, 6 stages) sub-passes,
         // instantiated directly: every thread owns a group in each (a radix-16 sub-pass would idle part of the workgroup)
         // and the radix-16 register footprint stays out of this kernel, whose y values live across the butterflies
         constexpr int R0 = PAIRS == 4 ? 3 : 2;
         if (bc.fp) {
-            ntt_phase_sub_fp<R0, true, NT>(a, bc, tid, lds, 0);
+            ntt_phase_sub_fp<R0, true, NT, true>(a, bc, tid, lds, 0);
             __syncthreads();
-            ntt_phase_sub_fp<2, true, NT>(a, bc, tid, lds, R0);
+            ntt_phase_sub_fp<2, true, NT, true>(a, bc, tid, lds, R0);
             __syncthreads();
-            ntt_phase_sub_fp<2, true, NT>(a, bc, tid, lds, R0 + 2);
+            ntt_phase_sub_fp<2, true, NT, true>(a, bc, tid, lds, R0 + 2);
         } else {
-            ntt_phase_sub<R0, true, NT>(a, bc, tid, lds, 0);
+            ntt_phase_sub<R0, true, NT, true>(a, bc, tid, lds, 0);
             __syncthreads();
-            ntt_phase_sub<2, true, NT>(a, bc, tid, lds, R0);
+            ntt_phase_sub<2, true, NT, true>(a, bc, tid, lds, R0);
             __syncthreads();
-            ntt_phase_sub<2, true, NT>(a, bc, tid, lds, R0 + 2);
+            ntt_phase_sub<2, true, NT, true>(a, bc, tid, lds, R0 + 2);
         }
         __syncthreads();
         ntt_phase_store<false, NT>(a, bc, tid, lds);
@@ -825,7 +841,7 @@ void launch_modup_ntt(Context& c, const BaseConvPlan* k, const BaseConvRows& row
     g.tgt_per_group = (k->nd + groups - 1) / groups;
     const long long nblocks = (long long)batch * (1 << (c.logn - a.tau)) * groups;
     LSA_REQUIRE(nblocks < (1LL << 31), "fused ModUp: grid too large");
-    const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
+    const size_t lds_bytes = ((size_t)lds_words(a.tau) + (2u << a.mu)) * sizeof(u64);   // tile + the target's twiddle pairs
     // algorithmic bytes: the conversion's ns + nd limbs plus the first half of nd limb transforms
     ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns + k->nd) + 8.0 * c.n * batch * (double)k->nd, s);
     switch (k->ns) {

@@ -95,6 +95,7 @@ struct NttBlockCtx {
     int mod;              // modulus index
     int fp;               // 1: FP64 engine
     int b, row;           // batch item and row inside it
+    const u64* tw_l;      // sub-passes instantiated with TWL: this limb's twiddles staged in LDS ({w, w'} pairs or doubles)
 };
 
 LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
@@ -118,6 +119,7 @@ LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
     c.b = b;
     c.row = row;
     c.fp = 0;
+    c.tw_l = nullptr;
     if (c.mod != LSA_ROW_SKIP) c.fp = a.allow_fp64 && (a.mods[c.mod].q >> LSA_FP64_MAX_BITS) == 0;
     return c;
 }
@@ -444,12 +446,13 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
 // One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass — integer (Shoup) engine.
 // LIN: the padded LDS addresses of a group's 2^RHO elements are an arithmetic progression (beta0 == 0 or >= 4), so one
 // add per element replaces the shift/add padding arithmetic.
-template <int RHO, bool LIN, int NT>
+// TWL: the twiddles come from the block's LDS copy (bc.tw_l, indexed like the limb's global slice) instead of global memory
+template <int RHO, bool LIN, int NT, bool TWL = false>
 LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const ModDev md = a.mods[bc.mod];
     const u64 q = md.q, q2 = 2 * md.q;
-    const u64* tw = a.tw + (((long long)bc.mod << a.logn) << 1);   // {w, ws} pairs
+    const u64* tw = TWL ? bc.tw_l : a.tw + (((long long)bc.mod << a.logn) << 1);   // {w, ws} pairs
     const int beta0 = a.lambda + a.mu - sig0 - RHO;  // lowest active bit of this sub-pass in l
     const int ngroups = 1 << (a.tau - RHO);
     const bool scale_here = a.inverse && a.apply_scale && a.s_lo + sig0 == 0;
@@ -514,11 +517,11 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
 }
 
 // The same sub-pass on the FP64 engine: LDS holds integer-valued doubles.
-template <int RHO, bool LIN, int NT>
+template <int RHO, bool LIN, int NT, bool TWL = false>
 LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const double q = (double)a.mods[bc.mod].q, qinv = 1.0 / q;
-    const double* tw = a.twd + ((long long)bc.mod << a.logn);
+    const double* tw = TWL ? reinterpret_cast<const double*>(bc.tw_l) : a.twd + ((long long)bc.mod << a.logn);
     const int beta0 = a.lambda + a.mu - sig0 - RHO;
     const int ngroups = 1 << (a.tau - RHO);
     const bool scale_here = a.inverse && a.apply_scale && a.s_lo + sig0 == 0;
