@@ -23,14 +23,14 @@ static constexpr int TPB = 256;
 #define LSA_STAMP(k) do { } while (0)
 #endif
 
-template <int NT>
+template <int NT, bool TWL = false>
 __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     int rho[4];
     const int np = ntt_split(a.mu, rho);
     if (!a.inverse) {
         int sig = 0;
         for (int i = 0; i < np; i++) {
-            ntt_phase_sub_dyn<NT>(a, bc, tid, lds, sig, rho[i]);
+            ntt_phase_sub_dyn<NT, TWL>(a, bc, tid, lds, sig, rho[i]);
             LSA_STAMP(3 + 2 * i);
             __syncthreads();
             LSA_STAMP(4 + 2 * i);
@@ -40,7 +40,7 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
         int sig = a.mu;
         for (int i = np - 1; i >= 0; i--) {
             sig -= rho[i];
-            ntt_phase_sub_dyn<NT>(a, bc, tid, lds, sig, rho[i]);
+            ntt_phase_sub_dyn<NT, TWL>(a, bc, tid, lds, sig, rho[i]);
             __syncthreads();
         }
     }
@@ -53,13 +53,23 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
 // NT: workgroup size = tile points / 16.  256 threads (4096-point tiles, 3-4 workgroups per CU) is the two-pass shape;
 // 512 / 1024 threads hold a whole N = 2^13 / 2^14 limb in LDS (69 / 136 KiB) and transform it in ONE pass: half the HBM
 // traffic of the two-pass plan, at one or two workgroups per CU.
-template <bool FZ, int NT>
+// TWL: the pass holds global stage 0 (strided first pass of a two-pass plan): its 2^mu twiddles are the same for every tile
+// of the limb and go through LDS -- one fetch per workgroup, issued with the tile loads, instead of one per sub-pass.
+template <bool FZ, int NT, bool TWL = false>
 __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
 #if LSA_NTT_TILES_PER_WG == 1
-    const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
+    NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
     if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
+    ulonglong2 twp = {0, 0};
+    if (TWL) {
+        bc.tw_l = lds + lds_words(a.tau);
+        if (tid < (1 << a.mu)) {
+            if (bc.fp) twp.x = d_to_bits(a.twd[((long long)bc.mod << a.logn) + tid]);
+            else twp = *reinterpret_cast<const ulonglong2*>(a.tw + (((long long)bc.mod << a.logn) << 1) + 2 * tid);
+        }
+    }
 #if defined(LSA_NTT_STAGGER)
     // Workgroups of one launch have identical phase lengths and start together, so the 3-4 co-resident ones run their
     // HBM phase and their butterfly phase in lockstep (measured: kernel time == copy-only time + compute-only time).
@@ -79,6 +89,14 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVE
 #endif
     LSA_STAMP(0);
     ntt_phase_load<FZ, NT>(a, bc, tid, lds);
+    if (TWL && tid < (1 << a.mu)) {
+        u64* tw_l = lds + lds_words(a.tau);
+        if (bc.fp) tw_l[tid] = twp.x;
+        else {
+            tw_l[2 * tid] = twp.x;
+            tw_l[2 * tid + 1] = twp.y;
+        }
+    }
     LSA_STAMP(1);
     __syncthreads();
     LSA_STAMP(2);
@@ -86,7 +104,7 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVE
     ntt_phase_store<FZ, NT>(a, bc, tid, lds);
     return;
 #endif
-    ntt_butterfly_phases<NT>(a, bc, tid, lds);
+    ntt_butterfly_phases<NT, TWL>(a, bc, tid, lds);
     ntt_phase_store<FZ, NT>(a, bc, tid, lds);
     LSA_STAMP(7);
 #else
@@ -121,6 +139,15 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVE
 template <int NT>
 static void ntt_launch_pass(const NttPassArgs& a, bool fused, long long nblocks, size_t lds_bytes, hipStream_t s) {
     LSA_REQUIRE((1 << a.tau) <= 2 * LSA_NTT_STAGE_PAIRS * NT, "ntt: tile larger than the staging registers");
+#if defined(LSA_NTT_TWL)
+    if (NT == 256 && a.s_lo == 0 && a.lambda != 0 && a.mu <= 8) {   // strided first pass of a two-pass plan: twiddles via LDS
+        const size_t bytes = lds_bytes + (2u << a.mu) * sizeof(u64);
+        if (fused) hipLaunchKernelGGL((k_ntt_pass<true, NT, true>), dim3((unsigned)nblocks), dim3(NT), bytes, s, a);
+        else hipLaunchKernelGGL((k_ntt_pass<false, NT, true>), dim3((unsigned)nblocks), dim3(NT), bytes, s, a);
+        LSA_HIP(hipGetLastError());
+        return;
+    }
+#endif
     if (lds_bytes > 65536) {   // whole-limb tiles: opt in to more than 64 KiB of dynamic LDS, once per kernel instance
         static bool raised[2] = {false, false};
         if (!raised[fused]) {

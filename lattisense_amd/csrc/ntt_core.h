@@ -606,17 +606,17 @@ LSA_HD int ntt_split(int mu, int* rho /*[4]*/) {
     return n;
 }
 
-template <bool LIN, int NT>
+template <bool LIN, int NT, bool TWL = false>
 LSA_HD void ntt_phase_sub_sel(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
     if (bc.fp) {
         switch (rho) {
-            case 1: ntt_phase_sub_fp<1, LIN, NT>(a, bc, tid, lds, sig0); break;
-            case 2: ntt_phase_sub_fp<2, LIN, NT>(a, bc, tid, lds, sig0); break;
+            case 1: ntt_phase_sub_fp<1, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
+            case 2: ntt_phase_sub_fp<2, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
 #if LSA_NTT_MAX_RHO >= 4
-            case 3: ntt_phase_sub_fp<3, LIN, NT>(a, bc, tid, lds, sig0); break;
-            default: ntt_phase_sub_fp<4, LIN, NT>(a, bc, tid, lds, sig0); break;
+            case 3: ntt_phase_sub_fp<3, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
+            default: ntt_phase_sub_fp<4, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
 #elif LSA_NTT_MAX_RHO == 3
-            default: ntt_phase_sub_fp<3, LIN, NT>(a, bc, tid, lds, sig0); break;
+            default: ntt_phase_sub_fp<3, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
 #else
             default: break;
 #endif
@@ -624,24 +624,24 @@ LSA_HD void ntt_phase_sub_sel(const NttPassArgs& a, const NttBlockCtx& bc, int t
         return;
     }
     switch (rho) {
-        case 1: ntt_phase_sub<1, LIN, NT>(a, bc, tid, lds, sig0); break;
-        case 2: ntt_phase_sub<2, LIN, NT>(a, bc, tid, lds, sig0); break;
+        case 1: ntt_phase_sub<1, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
+        case 2: ntt_phase_sub<2, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
 #if LSA_NTT_MAX_RHO >= 4
-        case 3: ntt_phase_sub<3, LIN, NT>(a, bc, tid, lds, sig0); break;
-        default: ntt_phase_sub<4, LIN, NT>(a, bc, tid, lds, sig0); break;
+        case 3: ntt_phase_sub<3, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
+        default: ntt_phase_sub<4, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
 #elif LSA_NTT_MAX_RHO == 3
-        default: ntt_phase_sub<3, LIN, NT>(a, bc, tid, lds, sig0); break;
+        default: ntt_phase_sub<3, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
 #else
         default: break;
 #endif
     }
 }
 
-template <int NT>
+template <int NT, bool TWL = false>
 LSA_HD void ntt_phase_sub_dyn(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0, int rho) {
     const int beta0 = a.lambda + a.mu - sig0 - rho;
     if (beta0 == 0 || beta0 >= 4)
-        ntt_phase_sub_sel<true, NT>(a, bc, tid, lds, sig0, rho);
+        ntt_phase_sub_sel<true, NT, TWL>(a, bc, tid, lds, sig0, rho);
     else
-        ntt_phase_sub_sel<false, NT>(a, bc, tid, lds, sig0, rho);
+        ntt_phase_sub_sel<false, NT, TWL>(a, bc, tid, lds, sig0, rho);
 }
