@@ -39,6 +39,7 @@
 #define LSA_MAX_PERIOD 192
 #define LSA_ROW_SKIP 0xFF
 #define LSA_FP64_MAX_BITS 47
+#define LSA_NTT_LAZY_BITS 58   // integer engine: moduli below 2^58 run their forward transforms without per-butterfly reduction
 #ifndef LSA_NTT_MAX_RHO
 #define LSA_NTT_MAX_RHO 4   // largest radix exponent of a sub-pass (2^rho points per thread in VGPRs)
 #endif
@@ -334,7 +335,7 @@ LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 #define LSA_NTT_STORE_CHUNK 4
 #endif
 struct NttStoreFix {   // per-block constants of the store-side conversions
-    bool fp, final_reduce, tail, with_base, merged;
+    bool fp, final_reduce, tail, with_base, merged, lazy;
     u64 q, qinv, k, k2;
     double qd, qinvd, kd, k2d;   // kd/k2d: the tail factors as plain doubles (FP64-engine limbs)
 };
@@ -350,7 +351,17 @@ LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
         if (r < 0) r += f.qd;   // one conditional add lands in [0, q): canonical on store
         return double_to_u52(r);
     }
-    if (f.final_reduce) v = csub(csub(v, 2 * f.q), f.q);
+    if (f.final_reduce) {
+#if defined(LSA_NTT_LAZY)
+        if (f.lazy) {   // forward transform of a lazy limb: values below 44q
+            v = csub(v, 32 * f.q);
+            v = csub(v, 16 * f.q);
+            v = csub(v, 8 * f.q);
+            v = csub(v, 4 * f.q);
+        }
+#endif
+        v = csub(csub(v, 2 * f.q), f.q);
+    }
     if (f.tail) {   // fused tail: the transformed value is consumed here and never stored
         if (f.merged) {
             v = sub_mod(mont_mul(va, f.k, f.q, f.qinv), v, f.q);
@@ -382,6 +393,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     NttStoreFix f;
     f.fp = bc.fp != 0;
     f.final_reduce = a.final_reduce != 0;
+    f.lazy = !a.inverse && (md.q >> LSA_NTT_LAZY_BITS) == 0;
     f.tail = FZ && a.fz_epi && a.final_reduce;
     f.q = md.q;
     f.qinv = md.qinv;
@@ -447,7 +459,11 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
 // LIN: the padded LDS addresses of a group's 2^RHO elements are an arithmetic progression (beta0 == 0 or >= 4), so one
 // add per element replaces the shift/add padding arithmetic.
 // TWL: the twiddles come from the block's LDS copy (bc.tw_l, indexed like the limb's global slice) instead of global memory
-template <int RHO, bool LIN, int NT, bool TWL = false>
+// LAZY (forward transforms of limbs with q < 2^58): the butterfly skips the conditional subtraction on its sum path.  Shoup's
+// product accepts any 64-bit operand and returns [0,2q), so both outputs grow by at most 2q per stage: from inputs below 4q a
+// whole transform of log N <= 20 stages stays below (4 + 2 log N) q <= 44q < 2^64, and the one reduction happens in the
+// final store (ntt_store_fix) -- 6 conditional subtractions per point per transform instead of one per butterfly.
+template <int RHO, bool LIN, int NT, bool TWL = false, bool LAZY = false>
 LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const ModDev md = a.mods[bc.mod];
@@ -478,7 +494,7 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
                         const int ti = 2 * (e >> (RHO - j));
-                        u64 U = csub(v[e], q2);
+                        u64 U = LAZY ? v[e] : csub(v[e], q2);
                         u64 T = shoup_mul_lazy(v[e + half], twj[ti], twj[ti + 1], q);
                         v[e] = U + T;
                         v[e + half] = sub64(U + q2, T);
@@ -623,6 +639,17 @@ LSA_HD void ntt_phase_sub_sel(const NttPassArgs& a, const NttBlockCtx& bc, int t
         }
         return;
     }
+#if defined(LSA_NTT_LAZY)
+    if (!a.inverse && (a.mods[bc.mod].q >> LSA_NTT_LAZY_BITS) == 0) {
+        switch (rho) {
+            case 1: ntt_phase_sub<1, LIN, NT, TWL, true>(a, bc, tid, lds, sig0); break;
+            case 2: ntt_phase_sub<2, LIN, NT, TWL, true>(a, bc, tid, lds, sig0); break;
+            case 3: ntt_phase_sub<3, LIN, NT, TWL, true>(a, bc, tid, lds, sig0); break;
+            default: ntt_phase_sub<4, LIN, NT, TWL, true>(a, bc, tid, lds, sig0); break;
+        }
+        return;
+    }
+#endif
     switch (rho) {
         case 1: ntt_phase_sub<1, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
         case 2: ntt_phase_sub<2, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;

@@ -21,7 +21,7 @@ def emu():
     srcs = [os.path.join(CSRC, f) for f in ("emu_ntt.cpp", "tables.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("ntt_core.h", "ntt_plan.h", "modarith.h", "tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-DLSA_EMULATE", "-o", so] + srcs)
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-DLSA_EMULATE"] + os.environ.get("LSA_EXTRA_FLAGS", "").split() + ["-o", so] + srcs)
     L = ctypes.CDLL(so)
     L.lsa_emu_ntt.restype = ctypes.c_int
     return L
