@@ -495,7 +495,11 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
                     if ((e & half) == 0) {
                         const int ti = 2 * (e >> (RHO - j));
                         u64 U = LAZY ? v[e] : csub(v[e], q2);
+#if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)   // diagnostic build: constant twiddle (wrong results, same arithmetic)
+                        u64 T = shoup_mul_lazy(v[e + half], (u64)(G + ti + 3), (u64)(G + ti + 5) << 40, q);
+#else
                         u64 T = shoup_mul_lazy(v[e + half], twj[ti], twj[ti + 1], q);
+#endif
                         v[e] = U + T;
                         v[e + half] = sub64(U + q2, T);
                     }
@@ -522,7 +526,11 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
                         const int ti = 2 * (e >> (RHO - j));
                         u64 U = v[e], V = v[e + half];   // both in [0,2q)
                         v[e] = csub(U + V, q2);
+#if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)
+                        v[e + half] = shoup_mul_lazy(sub64(U + q2, V), (u64)(G + ti + 3), (u64)(G + ti + 5) << 40, q);
+#else
                         v[e + half] = shoup_mul_lazy(sub64(U + q2, V), twj[ti], twj[ti + 1], q);
+#endif
                     }
                 }
             }
