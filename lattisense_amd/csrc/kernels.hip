@@ -995,7 +995,8 @@ void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u6
     const dim3 grid(grid1.x, (unsigned)((batch + g.bpt - 1) / g.bpt));
     // the register-resident key costs 8 VGPRs per digit slot: 5 and 6 digits (the 25Q+5P chains) get their own instantiations
     // instead of the 8-slot one (182 VGPRs, 2 waves per SIMD)
-    if (g.beta <= 4) hipLaunchKernelGGL(k_ks_mac<4>, grid, dim3(TPB), 0, s, g);
+    if (g.beta <= 2) hipLaunchKernelGGL(k_ks_mac<2>, grid, dim3(TPB), 0, s, g);   // low levels: 86 VGPRs, 5 waves per SIMD
+    else if (g.beta <= 4) hipLaunchKernelGGL(k_ks_mac<4>, grid, dim3(TPB), 0, s, g);
     else if (g.beta <= 5) hipLaunchKernelGGL(k_ks_mac<5>, grid, dim3(TPB), 0, s, g);
     else if (g.beta <= 6) hipLaunchKernelGGL(k_ks_mac<6>, grid, dim3(TPB), 0, s, g);
     else if (g.beta <= 8) hipLaunchKernelGGL(k_ks_mac<8>, grid, dim3(TPB), 0, s, g);
