@@ -682,6 +682,42 @@ struct Eval {
         }
         std::map<int, std::vector<size_t>> by_giant;
         for (size_t i = 0; i < mt.ks.size(); i++) by_giant[(mt.ks[i] / mt.n1) * mt.n1].push_back(i);
+        if (babies.size() <= 8 && by_giant.size() <= 8 && by_giant.size() > 1 && !std::getenv("LSA_BT_NO_MULTI_MAC")) {
+            // all inner sums in one launch: every baby-step ciphertext is read once, not once per giant step (same sums)
+            std::vector<int> bsteps;
+            std::vector<const u64*> cp;
+            std::vector<long long> cs;
+            for (auto& kv : babies) {
+                bsteps.push_back(kv.first);
+                cp.push_back(kv.second.data());
+                cs.push_back(stride(ct.level));
+            }
+            const int nb = (int)bsteps.size(), ng = (int)by_giant.size();
+            std::vector<const u64*> pp((size_t)ng * nb, nullptr);
+            std::vector<DCt> inner;
+            std::vector<u64*> op;
+            std::vector<int> gsteps;
+            int gi = 0;
+            for (auto& kv : by_giant) {
+                for (size_t i : kv.second) {
+                    const int bs = mt.ks[i] - kv.first;
+                    const int bi = (int)(std::find(bsteps.begin(), bsteps.end(), bs) - bsteps.begin());
+                    LSA_REQUIRE(bi < nb, "bootstrap: baby step without its rotation");
+                    pp[(size_t)gi * nb + bi] = mt.plains[i];
+                }
+                inner.push_back(alloc(ct.level, ct.scale * pt_scale));
+                op.push_back(inner.back().data());
+                gsteps.push_back(kv.first);
+                gi++;
+            }
+            launch_mac_plain_multi(c, nb, cp.data(), cs.data(), ng, pp.data(), op.data(), stride(ct.level), m, 2, L, rm2(ct.level), s);
+            for (int g2 = 0; g2 < ng; g2++) {
+                DCt r = rotate(inner[g2], gsteps[g2]);
+                acc = have ? add(acc, r) : r;
+                have = true;
+            }
+            return do_rescale ? rescale(acc) : acc;
+        }
         for (auto& kv : by_giant) {
             std::vector<std::pair<const u64*, const DCt*>> terms;
             for (size_t i : kv.second) terms.push_back({mt.plains[i], &baby(mt.ks[i] - kv.first)});

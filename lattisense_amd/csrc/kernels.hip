@@ -492,6 +492,83 @@ void launch_mac_plain(Context& c, int terms, const u64* const* ct, const long lo
     LSA_HIP(hipGetLastError());
 }
 
+// The inner sums of a baby-step / giant-step linear transform in ONE launch: out[g] = sum_b ct[b] * pt[g][b] for every giant
+// step g.  Each baby-step ciphertext is read once for all giant steps (k_mac_plain, one launch per giant step, re-reads all of
+// them every time): nb*polys + terms + ng*polys limb streams instead of terms*(polys + 1) + ng*polys.
+#define LSA_MACM_MAX 8
+struct MacPlainMultiArgs {
+    const u64* ct[LSA_MACM_MAX];
+    long long sct[LSA_MACM_MAX];
+    const u64* pt[LSA_MACM_MAX][LSA_MACM_MAX];   // [giant][baby], null = no such diagonal; shared by the batch
+    u64* out[LSA_MACM_MAX];
+    long long so;
+    const ModDev* mods;
+    int nb, ng, polys, limbs, logn;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+
+// grid: x = polys*limbs*(N/2/TPB), y = batch
+__global__ __launch_bounds__(TPB) void k_mac_plain_multi(MacPlainMultiArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;             // poly * limbs + limb
+    const int limb = row % g.limbs;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const ModDev m = g.mods[g.mod_of[limb]];
+    const long long b = blockIdx.y;
+    const long long coff = ((long long)row << g.logn) + x, poff = ((long long)limb << g.logn) + x;
+    ulonglong2 c[LSA_MACM_MAX];
+#pragma unroll
+    for (int i = 0; i < LSA_MACM_MAX; i++)
+        if (i < g.nb) c[i] = ld2(g.ct[i] + b * g.sct[i] + coff);
+    for (int gi = 0; gi < g.ng; gi++) {
+        u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0;   // at most 8 products of < q^2, q < 2^61: below q * 2^64
+#pragma unroll
+        for (int i = 0; i < LSA_MACM_MAX; i++) {
+            if (i < g.nb && g.pt[gi][i]) {
+                const ulonglong2 w = ld2(g.pt[gi][i] + poff);
+                mac128(h0, l0, c[i].x, w.x);
+                mac128(h1, l1, c[i].y, w.y);
+            }
+        }
+        u64 r0 = csub(mont_redc_lazy(h0, l0, m.q, m.qinv), m.q), r1 = csub(mont_redc_lazy(h1, l1, m.q, m.qinv), m.q);
+        r0 = mont_mul(r0, m.r2, m.q, m.qinv);            // sum * R^-1 -> sum
+        r1 = mont_mul(r1, m.r2, m.q, m.qinv);
+        st2(g.out[gi] + b * g.so + coff, r0, r1);
+    }
+}
+
+void launch_mac_plain_multi(Context& c, int nb, const u64* const* ct, const long long* sct, int ng, const u64* const* pt /*[ng*nb]*/,
+                            u64* const* out, long long so, int batch, int polys, int limbs, const RowMap& rm, hipStream_t s) {
+    if (batch <= 0 || nb <= 0 || ng <= 0) return;
+    LSA_REQUIRE(nb <= LSA_MACM_MAX && ng <= LSA_MACM_MAX, "too many baby or giant steps for one multiply-accumulate launch");
+    LSA_REQUIRE(rm.period == limbs && limbs <= LSA_MAX_PERIOD, "mac: row map must cover the limbs");
+    MacPlainMultiArgs g{};
+    int terms = 0;
+    for (int i = 0; i < nb; i++) {
+        g.ct[i] = ct[i];
+        g.sct[i] = sct[i];
+    }
+    for (int gi = 0; gi < ng; gi++) {
+        g.out[gi] = out[gi];
+        for (int i = 0; i < nb; i++) {
+            g.pt[gi][i] = pt[gi * nb + i];
+            terms += pt[gi * nb + i] != nullptr;
+        }
+    }
+    g.so = so;
+    g.mods = c.d_mods;
+    g.nb = nb;
+    g.ng = ng;
+    g.polys = polys;
+    g.limbs = limbs;
+    g.logn = c.logn;
+    int period;
+    fill_rowmap(g.mod_of, period, rm, c.nmod);
+    ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * limbs * batch * ((double)nb * polys + (double)terms * polys + (double)ng * polys), s);
+    hipLaunchKernelGGL(k_mac_plain_multi, ew_grid(c, polys * limbs, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
 // tensor product of two degree-1 ciphertexts: d0=a0*b0, d1=a0*b1+a1*b0, d2=a1*b1 (mega_ag_executors_gpu.cu:185,223)
 struct TensorArgs {
     const u64* a;

@@ -216,6 +216,8 @@ void launch_muladd(Context& c, EwOp op, const u64* a, const u64* b, const u64* a
 void launch_mac_plain(Context& c, int terms, const u64* const* ct, const long long* sct, const u64* const* pt,
                       const long long* spt, const u64* partial, long long spartial, u64* out, long long so, int batch,
                       int polys, int limbs, const RowMap& rm, hipStream_t s);
+void launch_mac_plain_multi(Context& c, int nb, const u64* const* ct, const long long* sct, int ng, const u64* const* pt,
+                            u64* const* out, long long so, int batch, int polys, int limbs, const RowMap& rm, hipStream_t s);
 // ring-t plaintext limb -> [level+1][N] residues: mode 0 centred lift from q_0 (CKKS), 1 direct (BFV multiply),
 // 2 scale-up by Q/t (BFV add/sub)
 void launch_lift_ringt(Context& c, int mode, int level, const u64* pt, long long spt, u64* out, long long sout, int batch,
