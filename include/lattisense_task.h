@@ -125,6 +125,10 @@ typedef struct {
 /* binds the native front-end's export/import executors to a task (calls bind_gpu_task_abi_bridge_executors) */
 int lsa_frontend_bind(fhe_task_handle handle);
 
+/* frees every pooled device / pinned buffer of the task (all devices); the next run allocates afresh.  Pools are keyed by
+ * (device, lane): one task handle may be run on any gpu_device, one run at a time (reference: README.md:195-202) */
+int lsa_task_trim_pools(fhe_task_handle handle);
+
 /* introspection used by tests and INTEGRATION.md examples */
 int lsa_task_counts(fhe_task_handle handle, int* n_data, int* n_compute, int* n_inputs, int* n_outputs);
 /* number of batched launch groups vs. compute nodes in the last run (how much graph-level batching happened) */

@@ -8,7 +8,8 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblattisense_amd.so")
+# LSA_NATIVE_LIB: an A/B build of the SAME library (lattisense_amd.build.build_variant) for measurements; never a fallback
+LIB_PATH = os.environ.get("LSA_NATIVE_LIB") or os.path.join(_HERE, "liblattisense_amd.so")
 
 _lib = None
 

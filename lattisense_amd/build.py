@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblattisense_amd.so")
 HIP_SOURCES = ["kernels.hip", "context.hip", "ops.hip", "bootstrap.hip", "c_api.hip", "task_runtime.hip"]
 CXX_SOURCES = ["tables.cpp", "task_graph.cpp"]
-HEADERS = ["modarith.h", "ntt_core.h", "ntt_plan.h", "tables.h", "lsa_internal.h", "task_graph.h", "mini_json.h",
+HEADERS = ["modarith.h", "ntt_core.h", "ntt_plan.h", "tables.h", "lsa_internal.h", "task_graph.h", "mini_json.h", "buf_pool.h",
            "../../include/lattisense_amd.h", "../../include/lattisense_task.h"]
 
 
@@ -64,5 +64,51 @@ def build_native(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, flags, verbose=False):
+    """A/B builds for measurement: the same library with extra compile flags, as lattisense_amd/variants/lib<name>.so
+    (selected at run time with LSA_NATIVE_LIB=<path>; diagnostics only -- tests and bench use the default build).
+    Objects are cached per variant; only sources whose text mentions one of the -D names are recompiled with the flags."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    build_native()
+    vdir = os.path.join(HERE, "variants")
+    objdir = os.path.join(CSRC, "build", "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hdr_text = "".join(open(h).read() for h in hdrs if os.path.exists(h))
+    macros = [f[2:].split("=")[0] for f in flags.split() if f.startswith("-D")]
+    objs = []
+    for src in [s for s in HIP_SOURCES + CXX_SOURCES if os.path.exists(os.path.join(CSRC, s))]:
+        sp = os.path.join(CSRC, src)
+        base_obj = os.path.join(CSRC, "build", src.replace(".", "_") + ".o")
+        text = open(sp).read()
+        affected = src.endswith(".hip") and (not macros or any(m in text or (m in hdr_text and src == "kernels.hip") for m in macros))
+        if not affected:
+            objs.append(base_obj)
+            continue
+        obj = os.path.join(objdir, src.replace(".", "_") + ".o")
+        objs.append(obj)
+        stamp = obj + ".flags"
+        if _stale(obj, [sp] + hdrs) or not os.path.exists(stamp) or open(stamp).read() != flags:
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+                   "-Wno-unused-result"] + flags.split() + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+            open(stamp, "w").write(flags)
+    out = os.path.join(vdir, "lib%s.so" % name)
+    tl = torch_lib_dir()
+    cmd = ["g++", "-shared", "-o", out] + objs
+    for d in ([tl] if tl else []) + ["/opt/rocm/lib"]:
+        cmd += ["-L" + d, "-Wl,-rpath," + d]
+    cmd += ["-lamdhip64", "-lpthread"]
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2], verbose=True))
+    else:
+        print(build_native(force="--force" in sys.argv, verbose=True))

@@ -1,5 +1,7 @@
 // kernels.hip — hand-written gfx950 kernels for the RNS hot path and their launchers.
 // HBM-bound integer work: 16 B/lane coalesced accesses, LDS-staged butterflies, no MFMA (no dense FP contraction here).
+#include <atomic>
+
 #include "lsa_internal.h"
 
 namespace lsa {
@@ -148,12 +150,15 @@ static void ntt_launch_pass(const NttPassArgs& a, bool fused, long long nblocks,
         return;
     }
 #endif
-    if (lds_bytes > 65536) {   // whole-limb tiles: opt in to more than 64 KiB of dynamic LDS, once per kernel instance
-        static bool raised[2] = {false, false};
-        if (!raised[fused]) {
+    if (lds_bytes > 65536) {   // whole-limb tiles: opt in to more than 64 KiB of dynamic LDS, once per kernel instance AND device
+        static std::atomic<unsigned long long> raised[2] = {{0}, {0}};   // bit d: done on device d (the attribute is per device)
+        int dev = 0;
+        LSA_HIP(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(raised[fused].load(std::memory_order_acquire) & bit)) {
             const void* fn = fused ? reinterpret_cast<const void*>(&k_ntt_pass<true, NT>) : reinterpret_cast<const void*>(&k_ntt_pass<false, NT>);
             LSA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised[fused] = true;
+            raised[fused].fetch_or(bit, std::memory_order_release);
         }
     }
     if (fused) hipLaunchKernelGGL((k_ntt_pass<true, NT>), dim3((unsigned)nblocks), dim3(NT), lds_bytes, s, a);

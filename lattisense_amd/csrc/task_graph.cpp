@@ -79,7 +79,7 @@ void TaskGraph::parse(const std::string& json_path) {
         if (is_custom_json(v)) {
             DatumNode::CustomProperty cp;
             cp.type = type_s;
-            if (v.contains("attributes")) cp.attributes = v["attributes"];
+            if (v.contains("attributes")) cp.attributes = lsa_attr_from(v["attributes"]);
             n.custom_prop = cp;
         } else {
             DatumNode::FheProperty fp;
@@ -113,7 +113,7 @@ void TaskGraph::parse(const std::string& json_path) {
         if (is_custom_json(v)) {
             ComputeNode::CustomProperty cp;
             cp.type = type_s;
-            if (v.contains("attributes")) cp.attributes = v["attributes"];
+            if (v.contains("attributes")) cp.attributes = lsa_attr_from(v["attributes"]);
             c.custom_prop = cp;
         } else {
             ComputeNode::FheProperty fp;

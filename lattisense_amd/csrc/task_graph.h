@@ -20,6 +20,40 @@
 #include "../../include/lattisense_task.h"
 #include "mini_json.h"
 
+// The node structs cross the executor boundary (custom executors receive `const ComputeNode& self` and may read
+// custom_prop->attributes).  Every member up to `attributes` has the reference's type, order and offset
+// (tests/test_abi_layout.py static_asserts it against the reference header where that is present, and against
+// tests/golden/abi_offsets.json everywhere); `attributes` itself is nlohmann::json in the reference.  A build inside the
+// reference tree defines LSA_WITH_NLOHMANN (and adds lib/ to the include path): the member then IS nlohmann::json, filled
+// from the parsed task file, and the structs are layout-identical including sizeof.  The stand-alone build has no
+// nlohmann and keeps this project's own JSON value there; executors that read attributes need the in-tree build.
+#if defined(LSA_WITH_NLOHMANN)
+#include "nlohmann/json.hpp"
+using LsaAttrJson = nlohmann::json;
+inline LsaAttrJson lsa_attr_from(const mjson::Value& v) {
+    switch (v.kind) {
+        case mjson::Value::Null: return nullptr;
+        case mjson::Value::Bool: return v.b;
+        case mjson::Value::Int: return v.is_unsigned ? LsaAttrJson((uint64_t)v.i) : LsaAttrJson(v.i);
+        case mjson::Value::Float: return v.f;
+        case mjson::Value::String: return v.s;
+        case mjson::Value::Array: {
+            LsaAttrJson a = LsaAttrJson::array();
+            for (auto& e : v.arr) a.push_back(lsa_attr_from(e));
+            return a;
+        }
+        default: {
+            LsaAttrJson o = LsaAttrJson::object();
+            for (auto& kv : v.obj) o[kv.first] = lsa_attr_from(kv.second);
+            return o;
+        }
+    }
+}
+#else
+using LsaAttrJson = mjson::Value;
+inline const LsaAttrJson& lsa_attr_from(const mjson::Value& v) { return v; }
+#endif
+
 using NodeIndex = uint64_t;
 struct ComputeNode;
 
@@ -58,7 +92,11 @@ enum class OperationType {
     IMPORT_FROM_ABI,     // C struct       -> caller handle (caller's executor, CPU)
     LOAD_TO_BACKEND,     // C struct       -> device datum  (this library)
     STORE_FROM_BACKEND,  // device datum   -> C struct      (this library)
-    FUSED_MULT_RELIN_RESCALE,  // internal (never in a task file): mult -> relin -> rescale chain, inputs [a, (b,) rlk]
+    // ---- everything above has the reference's enumerator values (mega_ag.h:68-91); values from here on are private to this
+    // backend, never appear in a task file and never on a node handed to a caller's executor as `self` (only backend nodes
+    // carry them; a custom executor that walks the graph must treat values >= BACKEND_PRIVATE_BEGIN as opaque)
+    BACKEND_PRIVATE_BEGIN = 1000,
+    FUSED_MULT_RELIN_RESCALE = 1000,  // mult -> relin -> rescale chain merged at load time, inputs [a, (b,) rlk]
 };
 
 struct DatumNode {
@@ -85,7 +123,7 @@ struct DatumNode {
     std::optional<FheProperty> fhe_prop;
     struct CustomProperty {
         std::string type;
-        mjson::Value attributes;
+        LsaAttrJson attributes;
     };
     std::optional<CustomProperty> custom_prop;
 };
@@ -114,7 +152,7 @@ struct ComputeNode {
     std::optional<FheProperty> fhe_prop;
     struct CustomProperty {
         std::string type;
-        mjson::Value attributes;
+        LsaAttrJson attributes;
     };
     std::optional<CustomProperty> custom_prop;
 

@@ -25,6 +25,7 @@
 #include <thread>
 #include <unordered_set>
 
+#include "buf_pool.h"
 #include "lsa_internal.h"
 #include "task_graph.h"
 
@@ -79,46 +80,36 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ device data
 // Buffers (device or pinned host) recycled across levels and run() calls: hipMalloc/hipFree and pinned allocation cost
-// milliseconds and synchronise the device, so a task keeps what it allocated.  Every device pool belongs to ONE lane (one
-// in-order stream), so handing a released device buffer to a later kernel is ordered after its earlier readers.
-struct BufPool {
-    bool pinned;
-    std::mutex mu;
-    std::multimap<size_t, u64*> free_list;
-    explicit BufPool(bool pinned_) : pinned(pinned_) {}
-    u64* take(size_t words) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            auto it = free_list.find(words);
-            if (it != free_list.end()) {
-                u64* p = it->second;
-                free_list.erase(it);
-                return p;
-            }
-        }
-        u64* p = nullptr;
-        if (pinned) LSA_HIP(hipHostMalloc((void**)&p, words * sizeof(u64), hipHostMallocDefault));
-        else LSA_HIP(hipMalloc((void**)&p, words * sizeof(u64)));
-        return p;
-    }
-    void give(size_t words, u64* p) {
-        std::lock_guard<std::mutex> lk(mu);
-        free_list.emplace(words, p);
-    }
-    ~BufPool() {
-        for (auto& kv : free_list) {
-            if (pinned) (void)hipHostFree(kv.second);
-            else (void)hipFree(kv.second);
-        }
-    }
-};
+// milliseconds and synchronise the device, so a task keeps what it allocated (buf_pool.h: best fit, a cap on what stays
+// pooled).  Every device pool belongs to ONE (device, lane) = one in-order stream, so handing a released device buffer to a
+// later kernel is ordered after its earlier readers, and a run on another device never sees this device's allocations.
+void* hip_buf_alloc(size_t bytes, int device, bool pinned) {
+    LSA_HIP(hipSetDevice(device));
+    void* p = nullptr;
+    if (pinned) LSA_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    else LSA_HIP(hipMalloc(&p, bytes));
+    return p;
+}
+void hip_buf_release(void* p, int device, bool pinned) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    if (pinned) (void)hipHostFree(p);
+    else (void)hipFree(p);
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+}
+size_t pool_cap_bytes(const char* env, double default_gib) {
+    const char* v = getenv(env);
+    return (size_t)((v ? atof(v) : default_gib) * 1073741824.0);
+}
 
 struct Slab {
     u64* ptr = nullptr;
-    size_t words = 0;
+    size_t words = 0;       // requested
+    size_t cap_words = 0;   // what the pool handed out (>= words)
     BufPool* pool;
-    Slab(BufPool& p, size_t w) : words(w), pool(&p) { ptr = p.take(w); }
-    ~Slab() { pool->give(words, ptr); }
+    Slab(BufPool& p, size_t w) : words(w), pool(&p) { ptr = p.take(w, &cap_words); }
+    ~Slab() { pool->give(cap_words, ptr); }
     Slab(const Slab&) = delete;
     Slab& operator=(const Slab&) = delete;
 };
@@ -256,17 +247,22 @@ struct fhe_task_handle_st {
     // subgraphs is pipelined over them: while lane A's chunk computes and copies its results back, lane B's chunk is
     // staged and copied in (PCIe is full duplex; the reference's runner overlaps nothing across its 2 streams' copies).
     // A released device buffer only returns to ITS lane's pool, so reuse stays ordered by that lane's in-order stream.
-    BufPool dev_pool0{false}, dev_pool1{false}, pin_pool{true};   // declared first: destroyed last
-    int cur_lane = 0;
-    std::shared_ptr<Slab> dslab(size_t words) { return std::make_shared<Slab>(cur_lane ? dev_pool1 : dev_pool0, words); }
+    // Pools are keyed by (device, lane): one task handle may be run on any device, one run() at a time (the reference's
+    // multi-GPU mode, README.md:195-202 / gpu_wrapper.cu:148-149); run() calls on one handle are serialised by run_mu.
+    LanePools pools{BufAllocator{hip_buf_alloc, hip_buf_release}, pool_cap_bytes("LSA_POOL_MAX_DEV_GIB", 48.0),
+                    pool_cap_bytes("LSA_POOL_MAX_PIN_GIB", 16.0)};   // declared first: destroyed last
+    std::mutex run_mu;
+    int cur_device = 0, cur_lane = 0;
+    std::shared_ptr<Slab> dslab(size_t words) { return std::make_shared<Slab>(pools.device_pool(cur_device, cur_lane), words); }
+    std::shared_ptr<Slab> pslab(size_t words) { return std::make_shared<Slab>(pools.pinned_pool(cur_device), words); }
     TaskGraph g;
     std::vector<std::vector<ComputeNode*>> levels;
     std::vector<std::vector<ComputeNode*>> shared_levels;                  // key export/load: before every chunk
     std::vector<std::vector<std::vector<ComputeNode*>>> chunk_levels;      // [chunk][level] -> nodes; empty: not pipelined
     std::map<int, std::unique_ptr<Context>> contexts;                      // key = 2*device + lane
     std::map<int, hipStream_t> streams;
-    std::vector<std::shared_ptr<Slab>> pending_free_[2];   // temporaries still referenced by enqueued work, per lane
-    std::vector<std::shared_ptr<Slab>>& pending_free() { return pending_free_[cur_lane]; }
+    std::map<int, std::vector<std::shared_ptr<Slab>>> pending_free_;   // temporaries still referenced by enqueued work, per (device, lane)
+    std::vector<std::shared_ptr<Slab>>& pending_free() { return pending_free_[LanePools::key(cur_device, cur_lane)]; }
     int last_gpu_nodes = 0, last_gpu_batches = 0;
     double last_ms = 0;
     struct BtDeleter {
@@ -453,15 +449,34 @@ struct fhe_task_handle_st {
         for (ComputeNode* node : nodes) {
             const DatumNode* in = node->input_nodes[0];
             const std::any& cs = avail.at(in->index);
+            // Every operand is sized from the graph's fhe_prop downstream (gather / run_gpu_bucket): a C struct that disagrees
+            // with the task's declaration would make those kernels read past the loaded slab, so it is refused here.
+            auto bad = [&](const std::string& what) {
+                throw Error(LSA_ERR_ARG, "input '" + in->id + "' (datum " + std::to_string(in->index) + "): " + what);
+            };
             if (in->datum_type == TYPE_CIPHERTEXT) {
                 auto ct = std::any_cast<std::shared_ptr<CCiphertext>>(cs);
-                LSA_REQUIRE(ct && ct->polys && ct->polys[0].components[0].n == c.n, "ciphertext C struct has a wrong ring degree");
-                for (int p = 0; p <= ct->degree; p++)
-                    LSA_REQUIRE(ct->polys[p].n_component == ct->level + 1, "ciphertext C struct: limb count != level+1");
+                if (!ct || !ct->polys) bad("null ciphertext C struct");
+                if (in->fhe_prop && (ct->level != in->fhe_prop->level || ct->degree != in->fhe_prop->degree))
+                    bad("ciphertext C struct has level/degree " + std::to_string(ct->level) + "/" + std::to_string(ct->degree) +
+                        ", the task declares " + std::to_string(in->fhe_prop->level) + "/" + std::to_string(in->fhe_prop->degree));
+                if (ct->level < 0 || ct->level >= c.nq || ct->degree < 0) bad("ciphertext level/degree out of range");
+                for (int p = 0; p <= ct->degree; p++) {
+                    if (!ct->polys[p].components || ct->polys[p].n_component != ct->level + 1) bad("ciphertext C struct: limb count != level+1");
+                    for (int j = 0; j <= ct->level; j++)
+                        if (ct->polys[p].components[j].n != c.n || !ct->polys[p].components[j].data) bad("ciphertext C struct has a wrong ring degree");
+                }
                 groups[{0, ct->degree + 1, ct->level}].push_back({node, ct, nullptr, ct->degree + 1, ct->level, 0});
             } else if (in->datum_type == TYPE_PLAINTEXT) {
                 auto pt = std::any_cast<std::shared_ptr<CPlaintext>>(cs);
-                LSA_REQUIRE(pt && pt->poly.components && pt->poly.components[0].n == c.n, "plaintext C struct has a wrong ring degree");
+                if (!pt || !pt->poly.components) bad("null plaintext C struct");
+                const bool ringt = is_ringt_node(in);
+                const int want = ringt ? 1 : (in->fhe_prop ? in->fhe_prop->level + 1 : pt->poly.n_component);
+                if (pt->poly.n_component != want)
+                    bad("plaintext C struct has " + std::to_string(pt->poly.n_component) + " limbs, the task declares " + std::to_string(want));
+                if (want < 1 || want > c.nq) bad("plaintext level out of range");
+                for (int j = 0; j < want; j++)
+                    if (pt->poly.components[j].n != c.n || !pt->poly.components[j].data) bad("plaintext C struct has a wrong ring degree");
                 groups[{1, 1, pt->poly.n_component - 1}].push_back({node, nullptr, pt, 1, pt->poly.n_component - 1, 0});
             } else {
                 key_nodes.push_back(node);
@@ -506,13 +521,23 @@ struct fhe_task_handle_st {
             k.comp = k.ksk->public_keys[0].polys[0].n_component;
             LSA_REQUIRE(k.comp == k.level + 1 + c.np, "key-switch key: limbs per polynomial != level+1+#special primes");
             LSA_REQUIRE(k.beta == (k.level + 1 + c.np - 1) / c.np, "key-switch key: digit count != ceil((level+1)/k)");
+            LSA_REQUIRE(k.level >= 0 && k.level < c.nq, "key-switch key: level out of range");
+            for (int d = 0; d < k.beta; d++) {
+                const CPublicKey& pk = k.ksk->public_keys[d];
+                LSA_REQUIRE(pk.polys && pk.degree == 1 && pk.level == k.level, "key-switch key: digits differ in level or degree");
+                for (int h = 0; h < 2; h++) {
+                    LSA_REQUIRE(pk.polys[h].components && pk.polys[h].n_component == k.comp, "key-switch key: limb count differs between digits");
+                    for (int j = 0; j < k.comp; j++)
+                        LSA_REQUIRE(pk.polys[h].components[j].n == c.n && pk.polys[h].components[j].data, "key-switch key has a wrong ring degree");
+                }
+            }
             k.off = total;
             total += (size_t)k.beta * 2 * k.comp * N;
             keys.push_back(std::move(k));
         }
         if (total == 0) return nullptr;
         // 2. gather limbs into a pinned staging slab, one H2D copy per group
-        auto hstage = std::make_shared<Slab>(pin_pool, total);
+        auto hstage = pslab(total);
         u64* host = hstage->ptr;
         struct Job {
             u64* dst;
@@ -622,7 +647,7 @@ struct fhe_task_handle_st {
         }
         // results land in ONE pooled pinned slab; the C structs handed to the caller's import executor only index it
         // (no malloc per limb, no second host copy).  The slab returns to the pool when the last struct is released.
-        auto hslab = std::make_shared<Slab>(pin_pool, total);
+        auto hslab = pslab(total);
         u64* host = hslab->ptr;
         // merge runs that are contiguous on the device into single copies
         for (size_t i = 0; i < items.size();) {
@@ -702,6 +727,12 @@ struct fhe_task_handle_st {
         for (auto* in : n->input_nodes) {
             sg += "|" + std::to_string((int)in->datum_type) + ":" + std::to_string(in->fhe_prop->level) + ":" +
                   std::to_string(in->fhe_prop->degree);
+            // pt, pt_mul and pt_ringt all arrive as TYPE_PLAINTEXT: the plaintext's treatment (lift, transform) is decided per
+            // bucket from its first node, so the flavour is part of the signature
+            if (in->datum_type == TYPE_PLAINTEXT) {
+                sg += (in->fhe_prop->p && in->fhe_prop->p->is_ringt) ? "r" : (in->fhe_prop->is_ntt ? "n" : "c");
+                if (in->fhe_prop->is_mform) sg += "m";
+            }
             // all nodes of a bucket must use the SAME key datum
             if (in->datum_type != TYPE_CIPHERTEXT && in->datum_type != TYPE_PLAINTEXT) sg += "#" + std::to_string(in->index);
         }
@@ -1045,7 +1076,12 @@ struct fhe_task_handle_st {
     // ---------------------------------------------------------------- run
     void run(CArgument* in_args, uint64_t n_in, CArgument* out_args, uint64_t n_out, progress_callback_t cb, void* user,
              int device) {
+        std::lock_guard<std::mutex> run_lock(run_mu);   // one run at a time per handle (the graph state is shared)
         const auto t_start = std::chrono::steady_clock::now();
+        cur_device = device;
+        cur_lane = 0;
+        pending_free_[LanePools::key(device, 0)];   // both lanes' entries exist before any finisher thread looks them up
+        pending_free_[LanePools::key(device, 1)];
         Context& c = context(device);
         hipStream_t s = streams.at(2 * device);
         // inputs: flatten every CArgument's handle array, consume in mega_ag.inputs order; all Galois-key data nodes share
@@ -1190,7 +1226,7 @@ struct fhe_task_handle_st {
                 auto t0 = tick();
                 LSA_HIP(hipStreamSynchronize(ls));
                 const double t_wait = ms_since(t0);
-                pending_free_[lane].clear();
+                pending_free_.at(LanePools::key(device, lane)).clear();
                 f->keep.clear();
                 auto& cl = chunk_levels[f->chunk];
                 t0 = tick();
@@ -1456,6 +1492,15 @@ int lsa_frontend_bind(fhe_task_handle handle) {
     return task_guard([&] {
         LSA_REQUIRE(handle != nullptr, "null task");
         handle->g.bind_bridge_executors(frontend_export(), frontend_import());
+    });
+}
+
+int lsa_task_trim_pools(fhe_task_handle handle) {
+    return task_guard([&] {
+        LSA_REQUIRE(handle != nullptr, "null task");
+        std::lock_guard<std::mutex> lk(handle->run_mu);
+        for (auto& kv : handle->pending_free_) kv.second.clear();
+        handle->pools.trim_all();
     });
 }
 
