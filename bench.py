@@ -45,7 +45,53 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=4)
     ap.add_argument("--log-slots", type=int, default=0, help="bootstrap workload: log2 of the packed slots (0 = dense, N/2)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch path only: every rank joins a gloo group, rank 0 prints what it sees (no GPU work; CPU test)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set)
+    BEFORE this process touches the GPU, wait for them and return the worst exit code.  Rank 0 prints the JSON line on the
+    shared stdout.  (The reference's multi-GPU usage is one device index per call, README.md:195-202; its harness
+    examples/benchmark_gpu/benchmark_gpu.cpp:27-52 takes the device the same way.)"""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.dry_launch:
+        import torch
+        have = torch.cuda.device_count()   # counts devices without initialising them
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def dry_launch(args):
+    """what --dry-launch ranks do: rendezvous over gloo exactly as the timed path does over RCCL, gather the ranks"""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = [None] * world
+    dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ["LOCAL_RANK"]), "pid": os.getpid()})
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks": seen, "max_rank": t.item()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def workload_config(name):
@@ -270,6 +316,17 @@ def run_bootstrap_workload(args):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (torchrun --nproc-per-node %d, or "
+                         "plain `bench.py --gpus %d`, which starts the ranks itself)" % (args.gpus, os.environ["WORLD_SIZE"], args.gpus, args.gpus))
+    if args.dry_launch:
+        if "WORLD_SIZE" not in os.environ:
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        return dry_launch(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and (args.workload == "bootstrap" or args.workload.startswith("task_")):
+        raise SystemExit("workload %s is a single-device measurement (replicas only): run it with --gpus 1" % args.workload)
     if args.workload == "bootstrap":
         return run_bootstrap_workload(args)
     if args.workload == "task_conv":

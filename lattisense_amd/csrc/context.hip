@@ -34,15 +34,6 @@ Context::Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_
     int mu_a = 0;
     if (const char* e = std::getenv("LSA_NTT_MU_A")) mu_a = std::atoi(e);   // A/B: stages of the first pass
     plan = make_ntt_plan(logn, LSA_NTT_TAU, mu_a);
-    if (logn >= 13 && logn - 6 <= LSA_NTT_TAU) {   // fused ModUp: first pass on 1024-point (6 stages) or 2048-point (7) tiles, 16 columns
-        const char* t = std::getenv("LSA_MODUP_TILE");
-        const int mu0 = (t && std::atoi(t) == 2048 && logn - 7 <= LSA_NTT_TAU) ? 7 : 6;
-        plan_modup.npass = 2;
-        plan_modup.pass[0] = {0, mu0, 4, mu0 + 4};
-        plan_modup.pass[1] = {mu0, logn - mu0, 0, LSA_NTT_TAU};
-        if (const char* e = std::getenv("LSA_FUSE_MODUP")) fuse_modup = e[0] == '1';
-        if (const char* e = std::getenv("LSA_MODUP_TGT")) modup_tgt = std::atoi(e);
-    }
     // N = 2^13 / 2^14: the whole limb also fits one workgroup's LDS (69 / 136 KiB) and can be transformed in a single pass
     // of 512 / 1024 threads: half the HBM traffic, but one or two workgroups per CU and R limbs fill only R CUs --
     // launch_ntt picks per launch; LSA_NTT_WIDE=0 / 1 forces never / always.

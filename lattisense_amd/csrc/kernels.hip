@@ -172,7 +172,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch
 }
 
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
-                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz, const NttPlan* plan_ovr, int step0) {
+                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz) {
     if (batch <= 0 || rows <= 0) return;
     LSA_REQUIRE(rm.period >= 1 && rm.period <= LSA_MAX_PERIOD, "ntt: bad row-map period");
     NttPassArgs a{};
@@ -187,7 +187,6 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
     a.allow_fp64 = c.fp64_ntt;
     if (fz) {
         LSA_REQUIRE(!inverse, "fused tails exist for forward transforms only");
-        LSA_REQUIRE(LSA_NTT_TILES_PER_WG == 1 || !fz->pro, "fused prologue needs the non-pipelined kernel");
         a.fz_epi = fz->epi;
         a.fz_pro = fz->pro;
         a.fz_limbs = fz->limbs;
@@ -233,8 +232,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         const long long limbs = (long long)active_rows * batch;
         wide = !fz && (c.logn == 13 ? limbs >= 1024 : (all_fp && limbs >= 512));
     }
-    if (plan_ovr) wide = false;
-    const NttPlan& plan = plan_ovr ? *plan_ovr : wide ? c.plan_wide : c.plan;
+    const NttPlan& plan = wide ? c.plan_wide : c.plan;
     {   // launches that mix both butterfly engines interleave their limbs (+1.4 % hmult / +2.2 % rotate NTT rate, profiles/r01/ab_row_inner.log)
         bool any_fp = false, any_int = false;
         for (int r = 0; r < rows; r++) {
@@ -254,11 +252,11 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = std::min(chunk, batch - b0);
         a.batch = nb;
-        for (int step = step0; step < plan.npass; step++) {   // step0 > 0: the earlier passes ran fused elsewhere (in place in dst)
+        for (int step = 0; step < plan.npass; step++) {
             const int k = inverse ? plan.npass - 1 - step : step;
             ntt_fill_pass(a, plan, c.logn, k, inverse ? 1 : 0);
-            a.src = (step == step0 ? src + (long long)b0 * src_stride : dst + (long long)b0 * dst_stride);
-            a.src_stride = step == step0 ? src_stride : dst_stride;
+            a.src = (step == 0 ? src + (long long)b0 * src_stride : dst + (long long)b0 * dst_stride);
+            a.src_stride = step == 0 ? src_stride : dst_stride;
             a.dst = dst + (long long)b0 * dst_stride;
             a.dst_stride = dst_stride;
             a.total_tiles = (long long)nb * rows * (1 << (a.logn - a.tau));
@@ -765,201 +763,6 @@ void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows
     else if (ns <= 8) launch_baseconv_ns<8>(ns, nd, grid, s, g);
     else if (ns <= 12) launch_baseconv_ns<12>(ns, nd, grid, s, g);
     else launch_baseconv_ns<LSA_BC_MAX_SRC>(ns, nd, grid, s, g);
-    LSA_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------------------------ ModUp + first NTT pass
-// One workgroup = one first-pass tile (1024 points: 64 strided rows x 16 columns, 6 stages; or 2048 points, 7 stages) of
-// one batch item and one GROUP of the digit's target limbs.  The tile's source coefficients are loaded once, y_i and the
-// float quotient v computed once (as in k_baseconv; 4 points per thread = 32 VGPRs of y for 4 sources), then target by
-// target: convert -> LDS -> the first-pass butterflies -> store in the layout the second pass reads.  The converted limb
-// is never written in the coefficient domain: per digit ns*g + nd + 2*nd limb streams instead of (ns + nd) + 2*nd + 2*nd.
-// EXPERIMENTAL (LSA_FUSE_MODUP=1): bit-exact, break-even against the two kernels it replaces.
-struct ModUpNttArgs {
-    NttPassArgs a;   // first-pass shape, dst / dst_stride = extension buffer, mods, twiddles (rows / mod_of unused)
-    const BaseConvConsts* k;
-    const u64* src;
-    long long ssrc;
-    int tgt_per_group;
-    BaseConvRows rows;
-};
-
-#ifndef LSA_MODUP_WAVES
-#define LSA_MODUP_WAVES 2   // workgroups per CU the register allocator must allow for 2048-point tiles (y and the butterfly state
-                            // live together); 1024-point tiles: 4 up to 4 sources (14 spilled VGPRs, still +1.5 %), 3 with 5
-#endif
-template <int NS, int PAIRS>   // PAIRS 16-byte pairs per thread: 2048-point (4) or 1024-point (2) first-pass tiles
-__global__ __launch_bounds__(LSA_NTT_THREADS, PAIRS == 4 ? LSA_MODUP_WAVES : NS <= 4 ? LSA_MODUP_WAVES + 2 : LSA_MODUP_WAVES + 1) void k_modup_ntt(ModUpNttArgs g) {
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    constexpr int NT = LSA_NTT_THREADS;
-    const NttPassArgs& a = g.a;
-    const BaseConvConsts& K = *g.k;
-    const int tid = threadIdx.x;
-    const long long bid = blockIdx.x;
-    const int tiles = 1 << (a.logn - a.tau);
-    const int b = (int)(bid % a.batch);
-    const long long rt = bid / a.batch;
-    const int tile = (int)(rt % tiles), zg = (int)(rt / tiles);
-    const NttTileMap tm = ntt_tile_map(a, tile);
-    const u64* src = g.src + (long long)b * g.ssrc;
-    int xs[PAIRS];
-#pragma unroll
-    for (int p = 0; p < PAIRS; p++) xs[p] = ntt_tile_index(tm, 2 * (tid + p * NT));
-    ulonglong2 xin[NS][PAIRS];
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int p = 0; p < PAIRS; p++) xin[i][p] = ld2(src + ((long long)g.rows.src_row[i] << a.logn) + xs[p]);
-    u64 y[NS][2 * PAIRS];
-    double vf[2 * PAIRS];
-#pragma unroll
-    for (int e = 0; e < 2 * PAIRS; e++) vf[e] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        const ModDev m = a.mods[K.src_mod[i]];
-        const double qf = K.qf[i], rf = K.rf[i];
-#pragma unroll
-        for (int p = 0; p < PAIRS; p++) {
-            y[i][2 * p] = mont_mul(xin[i][p].x, K.shat_inv_m[i], m.q, m.qinv);
-            y[i][2 * p + 1] = mont_mul(xin[i][p].y, K.shat_inv_m[i], m.q, m.qinv);
-        }
-#pragma unroll
-        for (int e = 0; e < 2 * PAIRS; e++) {   // the oracle's float sequence: correctly rounded y/q, summed in limb order
-            const double ad = (double)y[i][e], e0 = ad * rf;
-            vf[e] += __builtin_fma(__builtin_fma(-e0, qf, ad), rf, e0);
-        }
-    }
-    int v[2 * PAIRS];
-#pragma unroll
-    for (int e = 0; e < 2 * PAIRS; e++) v[e] = (int)(u64)vf[e];
-
-    const int j0 = zg * g.tgt_per_group, j1 = min(j0 + g.tgt_per_group, K.nd);
-    // the next target's correction terms v*S mod p_j (a per-lane gather) are fetched one target ahead: their latency then
-    // overlaps the current target's butterflies instead of heading its conversion
-    u64 vs_next[2 * PAIRS];
-#pragma unroll
-    for (int e = 0; e < 2 * PAIRS; e++) vs_next[e] = K.vs[min(j0, K.nd - 1)][v[e]];
-    for (int j = j0; j < j1; j++) {
-        u64 vs_cur[2 * PAIRS];
-#pragma unroll
-        for (int e = 0; e < 2 * PAIRS; e++) vs_cur[e] = vs_next[e];
-        {
-            const int jn = min(j + 1, K.nd - 1);
-#pragma unroll
-            for (int e = 0; e < 2 * PAIRS; e++) vs_next[e] = K.vs[jn][v[e]];
-        }
-        const int mod = K.dst_mod[j];
-        const ModDev m = a.mods[mod];
-        NttBlockCtx bc;
-        bc.base_src = 0;
-        bc.base_dst = (long long)b * a.dst_stride + ((long long)g.rows.dst_row[j] << a.logn);
-        bc.tile = tile;
-        bc.mod = mod;
-        bc.b = b;
-        bc.row = g.rows.dst_row[j];
-        bc.fp = a.allow_fp64 && (m.q >> LSA_FP64_MAX_BITS) == 0;
-        // this target's first-pass twiddles (indices below 2^mu: 1 KiB) go through LDS: fetched here, under the conversion,
-        // instead of once per sub-pass from global memory with nothing to hide the latency behind
-        u64* tw_l = lds + lds_words(a.tau);
-        bc.tw_l = tw_l;
-        ulonglong2 twp = {0, 0};
-        if (tid < (1 << a.mu)) {
-            if (bc.fp) twp.x = d_to_bits(a.twd[((long long)mod << a.logn) + tid]);
-            else twp = ld2(a.tw + (((long long)mod << a.logn) << 1) + 2 * tid);
-        }
-        u64 w[NS];
-#pragma unroll
-        for (int i = 0; i < NS; i++) w[i] = K.shat_m[j][i];
-#pragma unroll
-        for (int e = 0; e < 2 * PAIRS; e++) {
-            u64 h = 0, l = 0;
-#pragma unroll
-            for (int i = 0; i < NS; i++) mac128(h, l, y[i][e], w[i]);   // NS <= 5 products of < 2^61 * p_j: below p_j * 2^64
-            u64 r = csub(mont_redc_lazy(h, l, m.q, m.qinv), m.q);
-            r = sub_mod(r, vs_cur[e], m.q);
-            const int lidx = 2 * (tid + (e >> 1) * NT) + (e & 1);
-            lds[lds_addr(lidx)] = bc.fp ? d_to_bits(u52_to_double(r)) : r;
-        }
-        if (tid < (1 << a.mu)) {
-            if (bc.fp) tw_l[tid] = twp.x;
-            else {
-                tw_l[2 * tid] = twp.x;
-                tw_l[2 * tid + 1] = twp.y;
-            }
-        }
-        __syncthreads();
-        // the pass's stages as radix-8 / 4 / 4 (2048 points, 7 stages) or 4 / 4 / 4 (1024 points, 6 stages) sub-passes,
-        // instantiated directly: every thread owns a group in each (a radix-16 sub-pass would idle part of the workgroup)
-        // and the radix-16 register footprint stays out of this kernel, whose y values live across the butterflies
-        constexpr int R0 = PAIRS == 4 ? 3 : 2;
-        if (bc.fp) {
-            ntt_phase_sub_fp<R0, true, NT, true>(a, bc, tid, lds, 0);
-            __syncthreads();
-            ntt_phase_sub_fp<2, true, NT, true>(a, bc, tid, lds, R0);
-            __syncthreads();
-            ntt_phase_sub_fp<2, true, NT, true>(a, bc, tid, lds, R0 + 2);
-        } else {
-            ntt_phase_sub<R0, true, NT, true>(a, bc, tid, lds, 0);
-            __syncthreads();
-            ntt_phase_sub<2, true, NT, true>(a, bc, tid, lds, R0);
-            __syncthreads();
-            ntt_phase_sub<2, true, NT, true>(a, bc, tid, lds, R0 + 2);
-        }
-        __syncthreads();
-        ntt_phase_store<false, NT>(a, bc, tid, lds);
-        __syncthreads();   // the tile is rewritten by the next target
-    }
-}
-
-template <int NS>
-static void launch_modup_ntt_ns(const ModUpNttArgs& g, unsigned nblocks, size_t lds_bytes, hipStream_t s) {
-    if (g.a.tau == 11) hipLaunchKernelGGL((k_modup_ntt<NS, 4>), dim3(nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, g);
-    else hipLaunchKernelGGL((k_modup_ntt<NS, 2>), dim3(nblocks), dim3(LSA_NTT_THREADS), lds_bytes, s, g);
-}
-
-// the first pass of `plan` (a two-pass plan whose first tile is 2048 points) over the conversion of one digit; the caller
-// runs the second pass over the whole extension buffer afterwards (launch_ntt with the same plan and step0 = 1)
-void launch_modup_ntt(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, long long ssrc, u64* ext,
-                      long long sext, int batch, const NttPlan& plan, hipStream_t s) {
-    if (batch <= 0) return;
-    LSA_REQUIRE(k->ns >= 1 && k->ns <= 5, "fused ModUp: at most 5 source limbs");
-    const NttPassShape& p0 = plan.pass[0];
-    LSA_REQUIRE(plan.npass == 2 && p0.lambda == 4 && ((p0.tau == 11 && p0.mu == 7) || (p0.tau == 10 && p0.mu == 6)) && LSA_NTT_THREADS == 256,
-                "fused ModUp: needs a 2048-point / 7-stage or 1024-point / 6-stage first pass");
-    ModUpNttArgs g{};
-    NttPassArgs& a = g.a;
-    a.batch = batch;
-    a.rows = 1;
-    a.mods = c.d_mods;
-    a.tw = c.d_psi;
-    a.scale = c.d_scale;
-    a.twd = c.d_psi_d;
-    a.scaled = c.d_scale_d;
-    a.allow_fp64 = c.fp64_ntt;
-    a.period = 1;
-    a.row_step = 1;
-    ntt_fill_pass(a, plan, c.logn, 0, 0);
-    a.dst = ext;
-    a.dst_stride = sext;
-    g.k = k->dev;
-    g.src = src;
-    g.ssrc = ssrc;
-    g.rows = rows;
-    const int tg = c.modup_tgt > 0 ? c.modup_tgt : 7;
-    const int groups = (k->nd + tg - 1) / tg;   // ~7 targets per workgroup: y/v recomputed per group, grid kept above 2 k workgroups
-    g.tgt_per_group = (k->nd + groups - 1) / groups;
-    const long long nblocks = (long long)batch * (1 << (c.logn - a.tau)) * groups;
-    LSA_REQUIRE(nblocks < (1LL << 31), "fused ModUp: grid too large");
-    const size_t lds_bytes = ((size_t)lds_words(a.tau) + (2u << a.mu)) * sizeof(u64);   // tile + the target's twiddle pairs
-    // algorithmic bytes: the conversion's ns + nd limbs plus the first half of nd limb transforms
-    ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns + k->nd) + 8.0 * c.n * batch * (double)k->nd, s);
-    switch (k->ns) {
-        case 1: launch_modup_ntt_ns<1>(g, (unsigned)nblocks, lds_bytes, s); break;
-        case 2: launch_modup_ntt_ns<2>(g, (unsigned)nblocks, lds_bytes, s); break;
-        case 3: launch_modup_ntt_ns<3>(g, (unsigned)nblocks, lds_bytes, s); break;
-        case 4: launch_modup_ntt_ns<4>(g, (unsigned)nblocks, lds_bytes, s); break;
-        default: launch_modup_ntt_ns<5>(g, (unsigned)nblocks, lds_bytes, s); break;
-    }
     LSA_HIP(hipGetLastError());
 }
 

@@ -83,9 +83,6 @@ struct Context {
     int fp64_ntt = 1;               // use the FP64 butterfly engine for limbs with q < 2^47
     int tile_batch = 0;
     int fuse_tails = 1;             // ModDown / rescale element-wise tails fused into the NTT load/store phases
-    int fuse_modup = 0;             // ModUp conversion fused into the first NTT pass of the extension (LSA_FUSE_MODUP=1)
-    int modup_tgt = 0;              // targets per workgroup of the fused kernel (LSA_MODUP_TGT, default 7)
-    NttPlan plan_modup;             // its two-pass plan: 1024-point first-pass tiles (6 stages; LSA_MODUP_TILE=2048: 7), the rest in the second
     int dual_stream = 0;            // 1: overlap alternate tiles of an operator on an auxiliary stream (+5% throughput,
                                     // but per-kernel timings then include the co-running kernel; off for clean accounting)
     hipStream_t aux_stream = nullptr;
@@ -202,8 +199,7 @@ struct NttFusion {
     const u64* k2 = nullptr;     // epi == 2: out = (a*k - v + base) * k2
 };
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
-                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz = nullptr,
-                const NttPlan* plan_ovr = nullptr, int step0 = 0);
+                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz = nullptr);
 
 // limb-wise binary/unary ops on [batch][rows][N]; row r uses modulus rm.mod_of[r % period]
 enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MUL = 3 };
@@ -232,8 +228,6 @@ struct BaseConvRows {
 };
 void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
                      long long ssrc, long long sdst, hipStream_t s);
-void launch_modup_ntt(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, long long ssrc, u64* ext,
-                      long long sext, int batch, const NttPlan& plan, hipStream_t s);
 // key-switch inner product: acc[h][tl] = sum_d ext(d,tl) * key[d][h][tl];  ext(d,tl) = cx[tl] when tl is in digit d
 void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext,
                    const Key& key, u64* acc, long long sacc, int batch, hipStream_t s);

@@ -68,7 +68,6 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
     }
     // 2. per digit: exact conversion of the digit's limbs to every other limb of Q u P
     auto tl_mod = [&](int tl) { return tl < L ? tl : c.p_mod(tl - L); };
-    const bool fused = c.fuse_modup && np <= 5 && beta * T <= LSA_MAX_PERIOD;   // conversion + first NTT pass in one kernel
     for (int d = 0; d < beta; d++) {
         const int d0 = d * np, d1 = std::min(d0 + np, L);
         std::vector<int> src, dst;
@@ -82,8 +81,7 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
             rows.dst_row[dst.size()] = d * T + tl;
             dst.push_back(tl_mod(tl));
         }
-        if (fused) launch_modup_ntt(c, c.baseconv(src, dst, false), rows, conv_src, s_src, ext, s_ext, nb, c.plan_modup, s);
-        else launch_baseconv(c, c.baseconv(src, dst, false), rows, conv_src, ext, nb, s_src, s_ext, s);
+        launch_baseconv(c, c.baseconv(src, dst, false), rows, conv_src, ext, nb, s_src, s_ext, s);
     }
     // 3. extended limbs into the NTT domain (the digit's own limbs are taken from cx directly by the MAC)
     if (beta * T <= LSA_MAX_PERIOD) {
@@ -94,8 +92,7 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
                 const bool own = tl >= d * np && tl < std::min((d + 1) * np, L);
                 rm.mod_of[d * T + tl] = own ? LSA_ROW_SKIP : (unsigned char)tl_mod(tl);
             }
-        if (fused) launch_ntt(c, ext, ext, nb, s_ext, s_ext, beta * T, rm, false, s, nullptr, &c.plan_modup, 1);
-        else launch_ntt(c, ext, ext, nb, s_ext, beta * T, rm, false, s);
+        launch_ntt(c, ext, ext, nb, s_ext, beta * T, rm, false, s);
     } else {
         for (int d = 0; d < beta; d++) {
             RowMap rm;

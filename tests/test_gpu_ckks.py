@@ -24,14 +24,6 @@ def test_mult_relin_rescale_bit_exact_and_decrypts(n, lvl):
     _mult_relin_rescale_case(n, lvl)
 
 
-def test_fused_modup_first_pass_bit_exact(monkeypatch):
-    """LSA_FUSE_MODUP=1: the key switch's ModUp conversion runs inside the first NTT pass of the extension
-    (k_modup_ntt, N >= 2^13; experimental, off by default) -- same residues as the oracle."""
-    monkeypatch.setenv("LSA_FUSE_MODUP", "1")
-    _mult_relin_rescale_case(8192, 5)
-    _mult_relin_rescale_case(16384, 3)
-
-
 def _mult_relin_rescale_case(n, lvl):
     need_gpu()
     from oracle.client import Client, mean_precision_bits
@@ -283,6 +275,50 @@ def test_headline_shape_full_size():
         ctx.set_tile_batch(tile)
         got = ctx.download(ctx.ckks_mult_relin_rescale(lvl, da, db, k, batch), (batch, 2, lvl, n))
         assert np.array_equal(got, ref), (fp64, fuse, tile)
+
+
+def test_rotate_headline_shape_full_size():
+    """BASELINE configs[3] per-GPU shape at full size (CKKS N=2^16, 13 Q + 4 P limbs, Galois key switch): rotation by
+    5^1 mod 2N (the element bench.py --workload rotate times) and conjugation (2N-1) against the oracle on one ciphertext,
+    independent of the position in the batch, equal to the hoisted many-rotation entry point, and across butterfly engines /
+    fused tails / operator tiles.  Uniform-random key: parity does not need a decryptable one."""
+    need_gpu()
+    from lattisense_amd._native import check, lib
+    from lattisense_amd.device import DeviceContext, ALGO_CKKS
+    from oracle.pyoracle import Oracle
+    P = params.CKKS_DEFAULT[65536]
+    n, q, p = 65536, P["q"][:13], P["p"]
+    lvl = 12
+    ctx = DeviceContext(ALGO_CKKS, n, q, p)
+    o = Oracle(n, q, p, 0)
+    rng = np.random.default_rng(2027)
+    batch = 4
+    A = rand_ct(rng, q, 2, n, batch)
+    A[2] = A[0]                                    # the same ciphertext at two batch positions
+    da = ctx.upload(A)
+    beta = (lvl + 1 + len(p) - 1) // len(p)
+    keys, raw = {}, {}
+    for g in (5, 2 * n - 1):
+        key = np.empty((beta, 2, lvl + 1 + len(p), n), dtype=np.uint64)
+        for j, m in enumerate(q + p):
+            key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
+        raw[g] = key
+        keys[g] = ctx.upload_key(key, lvl)
+    refs = {}
+    for g in keys:
+        ref = ctx.download(ctx.ckks_rotate(lvl, da, g, keys[g], batch), (batch, 2, lvl + 1, n))
+        assert np.array_equal(ref[0], ref[2])
+        assert np.array_equal(ref[1], o.ckks_rotate(lvl, A[1], g, raw[g], lvl)), g
+        refs[g] = ref
+    outs = ctx.ckks_rotate_many(lvl, da, keys, batch)
+    for g in keys:
+        assert np.array_equal(ctx.download(outs[g], (batch, 2, lvl + 1, n)), refs[g]), g
+    for fp64, fuse, tile in [(0, 1, 2), (1, 0, 3), (0, 0, 1)]:
+        ctx.set_fp64_ntt(fp64)
+        check(lib().lsa_set_fuse_tails(ctx.h, fuse))
+        ctx.set_tile_batch(tile)
+        got = ctx.download(ctx.ckks_rotate(lvl, da, 5, keys[5], batch), (batch, 2, lvl + 1, n))
+        assert np.array_equal(got, refs[5]), (fp64, fuse, tile)
 
 
 def test_hoisted_rotations_equal_stand_alone_rotations():
