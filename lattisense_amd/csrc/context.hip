@@ -179,6 +179,15 @@ const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::ve
         for (int v = 0; v <= ns; v++) K->vs[j][v] = mul_mod_host(mul_mod_host((u64)v % pj, all, pj), scale, pj);
         K->half_dst[j] = mul_mod_host(mul_mod_host((all + pj - 1 % pj) % pj, (pj + 1) >> 1, pj), scale, pj);
     }
+    bool small = std::getenv("LSA_BC_NO_SPLIT") == nullptr;
+    for (int i = 0; i < ns; i++) small = small && (T.mod[src[i]] >> 58) == 0;
+    for (int j = 0; j < nd; j++) small = small && (T.mod[dst[j]] >> 58) == 0;
+    K->split29 = small ? 1 : 0;
+    for (int j = 0; j < nd; j++)
+        for (int i = 0; i < ns; i++) {
+            K->shat_lo[j][i] = (u32)(K->shat_m[j][i] & ((1u << 29) - 1));
+            K->shat_hi[j][i] = (u32)(K->shat_m[j][i] >> 29);
+        }
     use_device();
     BaseConvConsts* d = nullptr;
     LSA_HIP(hipMalloc((void**)&d, sizeof(BaseConvConsts)));
@@ -187,6 +196,7 @@ const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::ve
     pl.dev = d;
     pl.ns = ns;
     pl.nd = nd;
+    pl.split29 = small;
     bconv[key] = pl;
     return &bconv[key];
 }

@@ -648,7 +648,12 @@ struct BaseConvArgs {
 // NSMAX, so the source loads carry no guard and are all in flight before the first is consumed.  The target loop has a
 // fixed trip count (the tail group repeats its last target: same value stored twice by the same thread), so the per-target
 // constants are fetched up front instead of one scalar-load latency chain per target.
-template <int NSMAX, bool EXACT, int TGT>
+// SPLIT (every modulus of the conversion below 2^58, BaseConvConsts::split29): the products y_i * shat_ij are accumulated on
+// 29-bit halves -- y = y1 * 2^29 + y0, shat = w1 * 2^29 + w0, three 64-bit column sums y0 w0, y0 w1 + y1 w0, y1 w1 that
+// cannot overflow for up to 16 terms -- so every partial product is ONE v_mad_u64_u32 into its own accumulator pair: no
+// carries, no 64-bit addend built from register moves (the 128-bit form spends 14 instructions per term, 4 of them moves).
+// The columns are recombined into the 128-bit sum once per target; same sum, same REDC, same residues.
+template <int NSMAX, bool EXACT, int TGT, bool SPLIT = false>
 __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
     const BaseConvConsts& K = *g.k;
     const int x = (blockIdx.x * TPB + threadIdx.x) * 2;
@@ -686,11 +691,48 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
     const int v0 = (int)(u64)vf0, v1 = (int)(u64)vf1;
     // targets are split over blockIdx.z (each block recomputes y_i/v and converts TGT targets)
     const int j0 = blockIdx.z * TGT;
+    u32 ylo[SPLIT ? NSMAX : 1][2], yhi[SPLIT ? NSMAX : 1][2];
+    if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < NSMAX; i++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                ylo[i][e] = (u32)y[i][e] & ((1u << 29) - 1);
+                yhi[i][e] = (u32)(y[i][e] >> 29);
+            }
+    }
 #pragma unroll
     for (int jj = 0; jj < TGT; jj++) {
         const int j = min(j0 + jj, nd - 1);
         const ModDev m = g.mods[K.dst_mod[j]];
         u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0, r0 = 0, r1 = 0;
+        if (SPLIT) {
+            u64 c0[2] = {0, 0}, c1[2] = {0, 0}, c2[2] = {0, 0};
+#pragma unroll
+            for (int i = 0; i < NSMAX; i++) {
+                if (EXACT || i < ns) {
+                    const u32 w0 = K.shat_lo[j][i], w1 = K.shat_hi[j][i];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        c0[e] += (u64)ylo[i][e] * w0;
+                        c1[e] += (u64)ylo[i][e] * w1;
+                        c1[e] += (u64)yhi[i][e] * w0;
+                        c2[e] += (u64)yhi[i][e] * w1;
+                    }
+                }
+            }
+            // sum = c0 + c1 * 2^29 + c2 * 2^58 < 16 * 2^116: (hi, lo), below p_j * 2^64
+            u64 hs[2], ls[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const u64 a = c0[e] + (c1[e] << 29);
+                const u64 b = a + (c2[e] << 58);
+                ls[e] = b;
+                hs[e] = (c1[e] >> 35) + (c2[e] >> 6) + (a < c0[e] ? 1 : 0) + (b < a ? 1 : 0);
+            }
+            r0 = csub(mont_redc_lazy(hs[0], ls[0], m.q, m.qinv), m.q);
+            r1 = csub(mont_redc_lazy(hs[1], ls[1], m.q, m.qinv), m.q);
+        } else {
 #pragma unroll
         for (int i = 0; i < NSMAX; i++) {
             if (EXACT || i < ns) {
@@ -706,6 +748,7 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
         }
         r0 = add_mod(r0, csub(mont_redc_lazy(h0, l0, m.q, m.qinv), m.q), m.q);
         r1 = add_mod(r1, csub(mont_redc_lazy(h1, l1, m.q, m.qinv), m.q), m.q);
+        }
         r0 = sub_mod(r0, K.vs[j][v0], m.q);
         r1 = sub_mod(r1, K.vs[j][v1], m.q);
         if (K.centered) {
@@ -717,14 +760,19 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
 }
 
 template <int NSMAX, int TGT>
-static void launch_baseconv_nt(int ns, int nd, dim3 grid, hipStream_t s, const BaseConvArgs& g) {
+static void launch_baseconv_nt(int ns, int nd, bool split, dim3 grid, hipStream_t s, const BaseConvArgs& g) {
     grid.z = (unsigned)((nd + TGT - 1) / TGT);
+    if (split) {
+        if (ns == NSMAX) hipLaunchKernelGGL((k_baseconv<NSMAX, true, TGT, true>), grid, dim3(TPB), 0, s, g);
+        else hipLaunchKernelGGL((k_baseconv<NSMAX, false, TGT, true>), grid, dim3(TPB), 0, s, g);
+        return;
+    }
     if (ns == NSMAX) hipLaunchKernelGGL((k_baseconv<NSMAX, true, TGT>), grid, dim3(TPB), 0, s, g);
     else hipLaunchKernelGGL((k_baseconv<NSMAX, false, TGT>), grid, dim3(TPB), 0, s, g);
 }
 // targets per block: the candidate with the least total work ceil(nd/T) * (Y + T*C), Y = y/v phase ~ 2.5 target conversions
 template <int NSMAX>
-static void launch_baseconv_ns(int ns, int nd, dim3 grid, hipStream_t s, const BaseConvArgs& g) {
+static void launch_baseconv_ns(int ns, int nd, bool split, dim3 grid, hipStream_t s, const BaseConvArgs& g) {
     const int cand[3] = {4, 7, 13};
     int best = 4;
     double best_cost = 1e30;
@@ -735,9 +783,9 @@ static void launch_baseconv_ns(int ns, int nd, dim3 grid, hipStream_t s, const B
             best = T;
         }
     }
-    if (best == 4) launch_baseconv_nt<NSMAX, 4>(ns, nd, grid, s, g);
-    else if (best == 7) launch_baseconv_nt<NSMAX, 7>(ns, nd, grid, s, g);
-    else launch_baseconv_nt<NSMAX, 13>(ns, nd, grid, s, g);
+    if (best == 4) launch_baseconv_nt<NSMAX, 4>(ns, nd, split, grid, s, g);
+    else if (best == 7) launch_baseconv_nt<NSMAX, 7>(ns, nd, split, grid, s, g);
+    else launch_baseconv_nt<NSMAX, 13>(ns, nd, split, grid, s, g);
 }
 
 void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
@@ -755,14 +803,14 @@ void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows
     ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns + k->nd), s);
     const dim3 grid((unsigned)(c.n / (2 * TPB)), (unsigned)batch, 1);
     const int ns = k->ns, nd = k->nd;
-    if (ns <= 1) launch_baseconv_ns<1>(ns, nd, grid, s, g);
-    else if (ns <= 2) launch_baseconv_ns<2>(ns, nd, grid, s, g);
-    else if (ns <= 3) launch_baseconv_ns<3>(ns, nd, grid, s, g);
-    else if (ns <= 4) launch_baseconv_ns<4>(ns, nd, grid, s, g);
-    else if (ns <= 5) launch_baseconv_ns<5>(ns, nd, grid, s, g);
-    else if (ns <= 8) launch_baseconv_ns<8>(ns, nd, grid, s, g);
-    else if (ns <= 12) launch_baseconv_ns<12>(ns, nd, grid, s, g);
-    else launch_baseconv_ns<LSA_BC_MAX_SRC>(ns, nd, grid, s, g);
+    if (ns <= 1) launch_baseconv_ns<1>(ns, nd, k->split29, grid, s, g);
+    else if (ns <= 2) launch_baseconv_ns<2>(ns, nd, k->split29, grid, s, g);
+    else if (ns <= 3) launch_baseconv_ns<3>(ns, nd, k->split29, grid, s, g);
+    else if (ns <= 4) launch_baseconv_ns<4>(ns, nd, k->split29, grid, s, g);
+    else if (ns <= 5) launch_baseconv_ns<5>(ns, nd, k->split29, grid, s, g);
+    else if (ns <= 8) launch_baseconv_ns<8>(ns, nd, k->split29, grid, s, g);
+    else if (ns <= 12) launch_baseconv_ns<12>(ns, nd, k->split29, grid, s, g);
+    else launch_baseconv_ns<LSA_BC_MAX_SRC>(ns, nd, k->split29, grid, s, g);
     LSA_HIP(hipGetLastError());
 }
 

@@ -51,11 +51,17 @@ struct BaseConvConsts {
     u64 shat_m[LSA_BC_MAX_DST][LSA_BC_MAX_SRC];     // (S/q_i) mod p_j, Montgomery form
     u64 vs[LSA_BC_MAX_DST][LSA_BC_MAX_SRC + 1];     // v*S mod p_j, v = 0..ns
     u64 half_dst[LSA_BC_MAX_DST];                   // floor(S/2) mod p_j
+    // every source and target modulus below 2^58: shat_m split into 29-bit halves for the carry-free accumulate of
+    // k_baseconv<.., SPLIT> (shat_m[j][i] = hi * 2^29 + lo)
+    int split29;
+    u32 shat_lo[LSA_BC_MAX_DST][LSA_BC_MAX_SRC];
+    u32 shat_hi[LSA_BC_MAX_DST][LSA_BC_MAX_SRC];
 };
 
 struct BaseConvPlan {
     BaseConvConsts* dev = nullptr;
     int ns = 0, nd = 0;
+    bool split29 = false;
 };
 
 enum ProfKind { PROF_NTT = 0, PROF_BASECONV = 1, PROF_KSMAC = 2, PROF_TENSOR = 3, PROF_ELEMWISE = 4, LSA_PROF_KINDS = 5 };

@@ -1404,28 +1404,74 @@ ExecutorFunc frontend_export() {
                 });
                 break;
             }
-            default: throw std::runtime_error("native front-end cannot export custom data '" + in->id + "'");
+            default:
+                // custom input data (TYPE_CUSTOM: e.g. a message a custom "encode" node turns into a plaintext) never reaches the
+                // device: the opaque caller handle is handed through to the custom executors that consume it
+                // (cxx_abi_bridge_executors.h does the same with CustomData)
+                output = inputs.at(in->index);
+                break;
         }
     };
 }
 
-// C struct -> pre-allocated output handle (other_args[0], as in gpu_wrapper.cu:354-365)
+// an intermediate ciphertext handle owned by the run (a device result that a custom CPU node consumes, or a custom node's
+// input for the next device stage): header + limbs in one allocation, released with the last reference
+struct OwnedHostCiphertext {
+    lsa_host_ciphertext h;
+    std::vector<uint64_t> limbs;
+};
+std::shared_ptr<void> new_intermediate_ciphertext(int degree, int level, int n) {
+    auto o = std::make_shared<OwnedHostCiphertext>();
+    o->limbs.resize((size_t)(degree + 1) * (level + 1) * n);
+    o->h.level = level;
+    o->h.degree = degree;
+    o->h.n = n;
+    o->h.data = o->limbs.data();
+    return std::shared_ptr<void>(o, &o->h);   // aliasing: callers see the lsa_host_ciphertext, the block stays alive
+}
+
+// C struct -> pre-allocated output handle (other_args[0], as in gpu_wrapper.cu:354-365); without one (a device result that
+// feeds a custom CPU node) -> a fresh intermediate handle (cxx_abi_bridge_executors.h:428-431).  A custom node's own
+// output that is a task output arrives as a handle already and is copied into the caller's.
 ExecutorFunc frontend_import() {
     return [](ExecutionContext& ctx, const std::unordered_map<NodeIndex, std::any>& inputs, std::any& output, const ComputeNode& self) {
         const DatumNode* in = self.input_nodes[0];
-        auto ct = std::any_cast<std::shared_ptr<CCiphertext>>(inputs.at(in->index));
-        if (ctx.other_args.empty()) throw std::runtime_error("import: no output handle for '" + self.output_nodes[0]->id + "'");
-        auto* dst = (lsa_host_ciphertext*)std::any_cast<void*>(ctx.other_args[0]);
-        if (!dst || !dst->data) throw std::runtime_error("import: null output handle");
+        const std::any& src_any = inputs.at(in->index);
+        lsa_host_ciphertext* dst = nullptr;
+        std::shared_ptr<void> owned;
+        if (!ctx.other_args.empty()) {
+            dst = (lsa_host_ciphertext*)std::any_cast<void*>(ctx.other_args[0]);
+            if (!dst || !dst->data) throw std::runtime_error("import: null output handle");
+        }
+        if (auto* hp = std::any_cast<std::shared_ptr<void>>(&src_any)) {   // produced by a custom node: already a handle
+            auto* src = (lsa_host_ciphertext*)hp->get();
+            if (!src || !src->data) throw std::runtime_error("import: custom node '" + in->id + "' produced no ciphertext handle");
+            if (!dst) {
+                output = *hp;
+                return;
+            }
+            if (dst->level != src->level || dst->degree != src->degree || dst->n != src->n)
+                throw std::runtime_error("output ciphertext '" + self.output_nodes[0]->id + "' was allocated at level/degree " +
+                                         std::to_string(dst->level) + "/" + std::to_string(dst->degree) + ", result has " +
+                                         std::to_string(src->level) + "/" + std::to_string(src->degree));
+            memcpy(dst->data, src->data, sizeof(uint64_t) * (size_t)(src->degree + 1) * (src->level + 1) * src->n);
+            output = std::shared_ptr<void>(dst, [](void*) {});
+            return;
+        }
+        auto ct = std::any_cast<std::shared_ptr<CCiphertext>>(src_any);
+        const int n = ct->polys[0].components[0].n;
+        if (!dst) {
+            owned = new_intermediate_ciphertext(ct->degree, ct->level, n);
+            dst = (lsa_host_ciphertext*)owned.get();
+        }
         if (dst->level != ct->level || dst->degree != ct->degree)
             throw std::runtime_error("output ciphertext '" + self.output_nodes[0]->id + "' was allocated at level/degree " +
                                      std::to_string(dst->level) + "/" + std::to_string(dst->degree) + ", result has " +
                                      std::to_string(ct->level) + "/" + std::to_string(ct->degree));
-        const int n = ct->polys[0].components[0].n;
         for (int p = 0; p <= ct->degree; p++)
             for (int j = 0; j <= ct->level; j++)
                 memcpy(dst->data + ((size_t)p * (ct->level + 1) + j) * n, ct->polys[p].components[j].data, sizeof(uint64_t) * (size_t)n);
-        output = std::shared_ptr<void>(dst, [](void*) {});
+        output = owned ? owned : std::shared_ptr<void>(dst, [](void*) {});
     };
 }
 

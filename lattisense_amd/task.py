@@ -58,6 +58,8 @@ def _task_lib():
                                        ctypes.c_int]
         L.lsa_frontend_bind.restype = ctypes.c_int
         L.lsa_frontend_bind.argtypes = [ctypes.c_void_p]
+        L.lsa_task_trim_pools.restype = ctypes.c_int
+        L.lsa_task_trim_pools.argtypes = [ctypes.c_void_p]
         L.lsa_task_counts.restype = ctypes.c_int
         L.lsa_task_counts.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 4
         L.lsa_task_last_run_stats.restype = ctypes.c_int
@@ -108,6 +110,18 @@ class GaloisKey:
         self.h = HostGaloisKey(n, ctypes.cast(self._elts, c_u64p), ctypes.cast(self._arr, ctypes.POINTER(HostKsKey)))
 
 
+class CustomData:
+    """Opaque caller data of a custom node input (CustomData, cxx_argument.h:72,96-99): never reaches the device; the custom
+    executors the caller binds receive the handle (here: the address of `.h`, a {n, data} view of a uint64 vector)."""
+
+    class _View(ctypes.Structure):
+        _fields_ = [("n", ctypes.c_int), ("data", c_u64p)]
+
+    def __init__(self, values):
+        self.data = np.ascontiguousarray(values, dtype=np.uint64)
+        self.h = CustomData._View(self.data.size, self.data.ctypes.data_as(c_u64p))
+
+
 class Argument:
     """One task argument: id + list of host objects (CxxVectorArgument, cxx_argument.h:108-133)."""
 
@@ -118,7 +132,7 @@ class Argument:
     def _type(self):
         o = self.objects[0]
         return {Ciphertext: TYPE_CIPHERTEXT, Plaintext: TYPE_PLAINTEXT, KeySwitchKey: TYPE_RELIN_KEY,
-                GaloisKey: TYPE_GALOIS_KEY}[type(o)]
+                GaloisKey: TYPE_GALOIS_KEY, CustomData: TYPE_CUSTOM}[type(o)]
 
     def to_c(self, keep):
         n = len(self.objects)
@@ -150,6 +164,13 @@ class FheTaskGpu:
             self.close()
         except Exception:
             pass
+
+    def trim_pools(self):
+        """frees the task's pooled device / pinned buffers on every device (lsa_task_trim_pools)"""
+        L = _task_lib()
+        rc = L.lsa_task_trim_pools(self.h)
+        if rc:
+            raise LsaError(rc, L.lsa_last_error().decode())
 
     def counts(self):
         v = [ctypes.c_int() for _ in range(4)]

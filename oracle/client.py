@@ -163,10 +163,9 @@ class Client:
         return idx
 
     def _t_ctx(self):
-        if not hasattr(self, "_to"):
-            self._to = Oracle(self.n, [self.o.t], [], 0)
-            self._tidx = self._bfv_index()
-        return self._to, self._tidx
+        if not hasattr(self, "_tctx"):   # one assignment: custom executors call this from several runtime threads at once
+            self._tctx = (Oracle(self.n, [self.o.t], [], 0), self._bfv_index())
+        return self._tctx
 
     def bfv_encode(self, values):
         to, idx = self._t_ctx()

@@ -222,6 +222,14 @@ class Oracle:
         fn(self.h, op, lvl, ct.shape[0], _p(ct), _p(pt), _p(o))
         return o
 
+    def bfv_scale_up(self, lvl, pt):
+        """ring-t message limb (mod t) -> the full BFV plaintext of level `lvl` ([lvl+1][N], coefficient domain, scaled by Q/t
+        with rounding: Lattigo scaleUp) that ct + pt adds to c0"""
+        pt = np.ascontiguousarray(pt, dtype=np.uint64)
+        o = np.empty((lvl + 1, self.n), dtype=np.uint64)
+        lib().ora_bfv_scale_up(self.h, lvl, _p(pt), _p(o))
+        return o
+
     def bfv_mult_relin(self, lvl, a, b, rlk, klvl):
         o = np.empty((2, lvl + 1, self.n), dtype=np.uint64)
         lib().ora_bfv_mult_relin(self.h, lvl, _p(a), _p(b), _p(rlk), klvl, _p(o))
