@@ -503,11 +503,29 @@ def main():
 def cpu_baseline(workload, cfg):
     """Times the CPU oracle (a plain-C restatement, `kind: port`) on a bounded sample of the same workload,
     one ciphertext per thread over the host cores available to this process."""
+    import tempfile
     import numpy as np
-    from oracle.pyoracle import Oracle
+    from oracle import pyoracle
+    # the timing build of the oracle source: -O3 -march=native (same residues: tests/test_oracle_math.py), compiled here on
+    # the machine that runs it
+    flags = "gcc -O2 (checker build)"
+    try:
+        os.environ["LS_ORACLE_LIB"] = pyoracle.build_fast(tempfile.mkdtemp(prefix="lsa_cpu_baseline_"))
+        flags = "gcc -O3 -march=native"
+    except Exception:
+        os.environ.pop("LS_ORACLE_LIB", None)
+    Oracle = pyoracle.Oracle
     n, lvl = cfg["n"], cfg["level"]
     L = lvl + 1
     cores = max(1, min(len(os.sched_getaffinity(0)), 32))
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     o = Oracle(n, cfg["q"], cfg["p"], cfg["t"])
     rng = np.random.default_rng(0)
     qs = cfg["q"][:L]
@@ -526,7 +544,7 @@ def cpu_baseline(workload, cfg):
         for j, m in enumerate(qs + cfg["p"]):
             key[:, :, j, :] = rng.integers(0, m, size=(beta, 2, n), dtype=np.uint64)
     a, b = rand_ct(), rand_ct()
-    per_thread = 40 if workload == "ntt" else 1   # ~1-2 s of CPU work per thread either way
+    per_thread = 200 if workload == "ntt" else 6   # ~10-20 s of CPU work per thread either way
     done = []
 
     def work():
@@ -555,9 +573,9 @@ def cpu_baseline(workload, cfg):
         val, unit = units * 2 * 2 * L * 16.0 * n / dt / 1e9, "GB/s"
     else:
         val, unit = units / dt, "ciphertexts/s"
-    return {"value": val, "unit": unit, "cores": cores, "kind": "port",
-            "sample": "%d ciphertext op(s) of the same shape, one per thread, oracle/ls_oracle.c (gcc -O2), %.1f s wall"
-                      % (units, dt)}
+    return {"value": val, "unit": unit, "cores": cores, "kind": "port", "cpu_model": cpu_model, "host_cores_visible": os.cpu_count(),
+            "sample": "%d ciphertext op(s) of the same shape over %d threads (%d each), oracle/ls_oracle.c restatement (%s; not Lattigo), %.1f s wall"
+                      % (units, cores, per_thread, flags, dt)}
 
 
 if __name__ == "__main__":

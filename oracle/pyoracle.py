@@ -22,6 +22,16 @@ def build(force=False):
     return _LIB_PATH
 
 
+def build_fast(out_dir):
+    """the timing build of the same source (-O3 -march=native) compiled on THIS machine into out_dir; returns its path.
+    (A Barrett modmul in place of the 128-bit remainder was tried for this build and dropped: on the hosts measured the
+    hardware 128/64 division pipelines better -- 6 ns against 17 ns per NTT butterfly.)"""
+    out = os.path.join(out_dir, "libls_oracle_fast.so")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                           "-shared", "-o", out, os.path.join(_HERE, "ls_oracle.c")])
+    return out
+
+
 _lib = None
 
 
@@ -29,7 +39,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = ctypes.CDLL(_LIB_PATH)
+        # LS_ORACLE_LIB: bench.py's cpu_baseline leg points this at the -O3 -march=native timing build of the same source
+        L = ctypes.CDLL(os.environ.get("LS_ORACLE_LIB") or _LIB_PATH)
         L.ora_ctx_new.restype = ctypes.c_void_p
         L.ora_ctx_new.argtypes = [ctypes.c_int, u64p, ctypes.c_int, u64p, ctypes.c_int, ctypes.c_uint64]
         L.ora_ctx_free.argtypes = [ctypes.c_void_p]

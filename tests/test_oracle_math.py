@@ -1,6 +1,8 @@
 """Pins the CPU oracle by mathematics (the reference holds no golden vectors for this path):
 NTT == evaluation at odd powers of psi, NTT-convolution == the reference's negacyclic schoolbook definition
 (fhe_ops_lib/utils.cpp:87-102), base conversion == big-integer CRT, rescale == big-integer rounded division."""
+import os
+
 import numpy as np
 import pytest
 
@@ -156,3 +158,44 @@ def test_automorphism_ntt_matches_coefficient_domain():
         lhs = o.automorph_ntt(g, o.ntt(0, a))
         rhs = o.ntt(0, o.automorph_coeff(0, g, a))
         assert np.array_equal(lhs, rhs)
+
+
+def test_fast_mulmod_build_agrees(tmp_path):
+    """the -O3 -march=native timing build of the oracle (bench.py cpu_baseline) computes the same residues as the checker
+    build: mulmod on edge operands and a whole CKKS HMult+relin+rescale"""
+    import ctypes
+    import subprocess
+    import sys
+    from lattisense_amd import params
+    from oracle import pyoracle
+    fast = pyoracle.build_fast(str(tmp_path))
+    L = ctypes.CDLL(fast)
+    L.ora_mulmod.restype = ctypes.c_uint64
+    L.ora_mulmod.argtypes = [ctypes.c_uint64] * 3
+    ref = pyoracle.lib()
+    ref.ora_mulmod.restype = ctypes.c_uint64
+    ref.ora_mulmod.argtypes = [ctypes.c_uint64] * 3
+    rng = np.random.default_rng(3)
+    for q in params.CKKS_DEFAULT[65536]["q"][:3] + params.CKKS_BOOTSTRAP_65536["p"][:2] + [3, 5, 65537]:
+        xs = [0, 1, q - 1, q // 2] + [int(v) for v in rng.integers(0, q, size=200, dtype=np.uint64)]
+        for a in xs[:40]:
+            for b in xs[::7]:
+                assert L.ora_mulmod(a, b, q) == ref.ora_mulmod(a, b, q) == a * b % q
+    # a whole operator in a child process that loads the fast build through LS_ORACLE_LIB
+    code = ("import numpy as np, hashlib\nfrom lattisense_amd import params\nfrom oracle.pyoracle import Oracle\n"
+            "P = params.CKKS_DEFAULT[16384]\nn, q, p = 2048, P['q'][:4], P['p']\no = Oracle(n, q, p, 0)\n"
+            "rng = np.random.default_rng(1)\n"
+            "def ct():\n    c = np.empty((2, 4, n), dtype=np.uint64)\n"
+            "    for j, m in enumerate(q): c[:, j] = rng.integers(0, m, size=(2, n), dtype=np.uint64)\n    return c\n"
+            "k = np.empty((2, 2, 6, n), dtype=np.uint64)\n"
+            "for j, m in enumerate(q + p): k[:, :, j] = rng.integers(0, m, size=(2, 2, n), dtype=np.uint64)\n"
+            "print(hashlib.sha256(o.ckks_mult_relin_rescale(3, ct(), ct(), k, 3).tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_lib in (None, fast):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("LS_ORACLE_LIB", None)
+        if env_lib:
+            env["LS_ORACLE_LIB"] = env_lib
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 64
