@@ -345,6 +345,44 @@ class Bootstrapper:
         self.cts[0] = {k: d * g for k, d in self.cts[0].items()}
         self.out_scale = out_scale
 
+    def expected_constants(self, in_scale, top_level):
+        """This module's OWN floating-point constants for a bootstrap of a level-0 ciphertext at `in_scale`: every diagonal of
+        every CoeffsToSlots / SlotsToCoeffs matrix encoded the way linear_transform() would encode it (level, scale, giant-step
+        pre-rotation), keyed like `plains`, and the 32 Chebyshev coefficients.  Nothing here comes from the device library:
+        tests/test_gpu_bootstrap.py compares the device plan's constants against these within a stated tolerance."""
+        ev = self.ev
+        n = self.n
+        q0 = ev.q(0)
+        c = max(1, int(round(q0 / (self.mr * in_scale))))
+        d1 = in_scale * c
+
+        def encode_matrix(diags, level):
+            ks = sorted(diags)
+            out = {}
+            n1 = bsgs_split(ks, n, 2.0) if len(ks) >= 3 else 0
+            for k in ks:
+                g = (k // n1) * n1 if n1 else 0
+                out[k] = ev.encode(np.roll(diags[k], g), level, float(ev.q(level)))
+            return out
+
+        plains = {}
+        level = top_level
+        for i, m in enumerate(self.cts):
+            plains[("cts", i)] = encode_matrix(m, level)
+            level -= 1
+        u_level = level
+        level -= 5 + self.r                          # EvalMod: 32 Chebyshev coefficients (5 levels) + r double-angle steps
+        natural = self.evalmod_out_scale(u_level) * 2 * np.pi * d1 / q0
+        stc = list(self.stc)
+        if self.out_scale is not None:
+            kappa = self.out_scale / natural
+            stc[0] = {k: d * kappa for k, d in stc[0].items()}
+        for i, m in enumerate(stc):
+            plains[("stc", i)] = encode_matrix(m, level)
+            level -= 1
+        coeffs = chebyshev_coeffs(lambda x: np.cos(2 * np.pi * (self.K * x - 0.25) / (1 << self.r)), 31)
+        return plains, np.asarray(coeffs, dtype=np.float64), level
+
     def mod_raise(self, ct, top_level):
         """level-0 ciphertext -> same polynomials (centred mod q_0) over Q_top"""
         o = self.ev.o

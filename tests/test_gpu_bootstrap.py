@@ -210,3 +210,83 @@ def test_multiply_then_bootstrap_task():
         assert re >= 10 and im >= 10
     plan.close()
     t.close()
+
+
+@pytest.mark.parametrize("log_n", [11, 13])
+def test_device_constants_against_independently_computed_ones(log_n):
+    """The only floating-point work of the device bootstrap is its CONSTANTS (encoded DFT diagonals, Chebyshev coefficients,
+    lsa_bootstrap_plaintext / lsa_bootstrap_chebyshev).  The bit-exactness tests above feed them to the oracle program; here
+    they are checked against the oracle module's OWN computation (numpy FFT-layer algebra + chebinterpolate,
+    oracle/ckks_bootstrap.py expected_constants -- nothing shared with csrc/bootstrap.hip).  Tolerance: every encoded
+    coefficient within 2^-30 of the plaintext scale (the scale is the level's prime, 2^39..2^60, and both sides round
+    double-precision products of magnitude <= scale, so the honest bound is a few ulp = scale * 2^-50; 2^-30 leaves room for the
+    different evaluation order of the merged layers), identical across the limbs of a plaintext; Chebyshev coefficients
+    within 1e-9 absolute (they enter at scale 2^60: an error of 1e-9 there is 30 bits below the 10-bit precision the
+    reference asserts)."""
+    need_gpu()
+    from lattisense_amd.device import BootstrapPlan
+    from oracle.ckks_bootstrap import Bootstrapper, Evaluator
+    B, N, o, c, ctx = _setup(log_n, 32, 5)
+    top = len(B["q"]) - 1
+    D = float(2 ** 40)
+    plan = BootstrapPlan(ctx, in_scale=D, out_scale=D)
+    ev = Evaluator.__new__(Evaluator)          # no keys needed: only q() and encode() are used
+    ev.o, ev.c, ev.n = o, c, N
+    want, coeffs, out_level = Bootstrapper(ev, out_scale=D).expected_constants(D, top)
+    assert out_level == plan.out_level
+    dev = plan.oracle_plains()
+    assert sorted(dev) == sorted(want)
+    worst = 0.0
+    for key in sorted(want):
+        assert sorted(dev[key]) == sorted(want[key]), key          # the same diagonal index set
+        for k in want[key]:
+            a, b = dev[key][k], want[key][k]
+            assert a.shape == b.shape, (key, k)
+            lvl = a.shape[0] - 1
+            deltas = []
+            for j in (0, lvl):
+                q = o.mod[j]
+                d = (o.intt(j, a[j]).astype(object) - o.intt(j, b[j]).astype(object)) % q
+                d = np.array([int(x) - q if int(x) > q // 2 else int(x) for x in d], dtype=np.float64)
+                deltas.append(d)
+            assert np.array_equal(deltas[0], deltas[1]), (key, k)   # one integer polynomial, not per-limb noise
+            rel = np.max(np.abs(deltas[0])) / float(o.mod[lvl])
+            worst = max(worst, rel)
+            assert rel < 2.0 ** -30, (key, k, rel)
+    dc = np.max(np.abs(plan.chebyshev()[: len(coeffs)] - coeffs))
+    assert dc < 1e-9, dc
+    print("max relative constant deviation 2^%.1f, chebyshev %.2e" % (np.log2(max(worst, 1e-300)), dc))
+    plan.close()
+
+
+def test_bootstrap_reference_parameter_set_full_size():
+    """The reference's bootstrap test at its real size (unittests/test_gpu_ckks.cpp:763-781, parameter set
+    unittests/fixture.hpp:120-162 = frontend default N16QP1546H192H32): N = 2^16, 25 Q + 5 P primes, dense packing, main secret
+    of Hamming weight 192, ephemeral secret of weight 32 (swk_dts / swk_std), REAL keys from the test client -- relinearisation
+    key, the 47 planner rotations + conjugation, both switching keys.  One level-0 ciphertext in, level 9 out, and the
+    reference's own assertion: decrypted mean precision >= 10 bits.  (The oracle program is not replayed at this size: a
+    CPU bootstrap takes minutes; its bit-exactness is pinned at N = 2^10..2^11 above.)"""
+    need_gpu()
+    from lattisense_amd.device import BootstrapPlan
+    from oracle.client import Client, mean_precision_bits
+    B, N, o, c, ctx = _setup(16, 192, 2026)
+    top = len(B["q"]) - 1
+    D = float(2 ** 40)
+    plan = BootstrapPlan(ctx, in_scale=D, out_scale=D)
+    assert plan.out_level == 9 and not plan.sparse and len(plan.galois_elements) == 48
+    sparse = Client(o, seed=2027, hamming=32)
+    rlk = ctx.upload_key(c.gen_relin_key(top), top)
+    glk = {}
+    for e in plan.galois_elements:             # one key at a time: 157 MB each on the host, resident on the device afterwards
+        glk[e] = ctx.upload_key(c.gen_galois_key(e, top), top)
+    kd = ctx.upload_key(c.gen_switching_key(c.s_ntt, sparse.s_ntt, 0), 0)
+    ks = ctx.upload_key(c.gen_switching_key(sparse.s_ntt, c.s_ntt, top), top)
+    rng = np.random.default_rng(16)
+    z = rng.uniform(-1, 1, N // 2) + 1j * rng.uniform(-1, 1, N // 2)
+    ct = c.ckks_encrypt(z, 0, D)[None]
+    out = plan.run(ctx.upload(ct), 1, rlk, glk, kd, ks)
+    got = ctx.download(out, (1, 2, plan.out_level + 1, N))[0]
+    re, im = mean_precision_bits(z, c.ckks_decrypt(got, D))
+    print("N=2^16 bootstrap: level 0 -> %d, mean precision %.1f / %.1f bits" % (plan.out_level, re, im))
+    assert re >= 10 and im >= 10
+    plan.close()
