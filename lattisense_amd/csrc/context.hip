@@ -187,7 +187,13 @@ const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::ve
         for (int i = 0; i < ns; i++) {
             K->shat_lo[j][i] = (u32)(K->shat_m[j][i] & ((1u << 29) - 1));
             K->shat_hi[j][i] = (u32)(K->shat_m[j][i] >> 29);
+            K->shat_sum[j][i] = K->shat_lo[j][i] + K->shat_hi[j][i];
         }
+    for (int j = 0; j < nd; j++) {
+        const u64 pj = T.mod[dst[j]];
+        K->corr_a[j] = to_mont_host((pj - K->vs[j][1]) % pj, pj);   // vs[j][1] = S (times the P^-1 scale) mod p_j
+        K->corr_b[j] = centered ? to_mont_host((pj - K->half_dst[j]) % pj, pj) : 0;
+    }
     use_device();
     BaseConvConsts* d = nullptr;
     LSA_HIP(hipMalloc((void**)&d, sizeof(BaseConvConsts)));

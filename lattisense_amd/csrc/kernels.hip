@@ -653,9 +653,23 @@ struct BaseConvArgs {
 // cannot overflow for up to 16 terms -- so every partial product is ONE v_mad_u64_u32 into its own accumulator pair: no
 // carries, no 64-bit addend built from register moves (the 128-bit form spends 14 instructions per term, 4 of them moves).
 // The columns are recombined into the 128-bit sum once per target; same sum, same REDC, same residues.
+// The conversion plan and the modulus table are read through the CONSTANT address space: they are never written while a
+// kernel runs, and only then may the compiler keep their (wave-uniform) loads on the scalar unit after the kernel's first
+// store -- as plain global loads 86 of a thread's 103 vector-memory instructions were broadcast reads of these constants,
+// queued in front of its 13 stores.
+#define LSA_CONST_AS __attribute__((address_space(4)))
+__device__ __forceinline__ ModDev ld_mod(const LSA_CONST_AS ModDev* t, int i) {
+    ModDev m;
+    m.q = t[i].q;
+    m.qinv = t[i].qinv;
+    m.r2 = t[i].r2;
+    m.r1 = t[i].r1;
+    return m;
+}
 template <int NSMAX, bool EXACT, int TGT, bool SPLIT = false>
 __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
-    const BaseConvConsts& K = *g.k;
+    const LSA_CONST_AS BaseConvConsts& K = *(const LSA_CONST_AS BaseConvConsts*)g.k;
+    const LSA_CONST_AS ModDev* const mods_c = (const LSA_CONST_AS ModDev*)g.mods;
     const int x = (blockIdx.x * TPB + threadIdx.x) * 2;
     const long long b = blockIdx.y;
     const u64* src = g.src + b * g.ssrc + x;
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
 #pragma unroll
     for (int i = 0; i < NSMAX; i++) {
         if (EXACT || i < ns) {
-            const ModDev m = g.mods[K.src_mod[i]];
+            const ModDev m = ld_mod(mods_c, K.src_mod[i]);
             ulonglong2 v = xin[i];
             if (K.centered) {
                 v.x = add_mod(v.x, K.half_src[i], m.q);
@@ -691,7 +705,7 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
     const int v0 = (int)(u64)vf0, v1 = (int)(u64)vf1;
     // targets are split over blockIdx.z (each block recomputes y_i/v and converts TGT targets)
     const int j0 = blockIdx.z * TGT;
-    u32 ylo[SPLIT ? NSMAX : 1][2], yhi[SPLIT ? NSMAX : 1][2];
+    u32 ylo[SPLIT ? NSMAX : 1][2], yhi[SPLIT ? NSMAX : 1][2], ysum[SPLIT ? NSMAX : 1][2];
     if (SPLIT) {
 #pragma unroll
         for (int i = 0; i < NSMAX; i++)
@@ -699,39 +713,62 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
             for (int e = 0; e < 2; e++) {
                 ylo[i][e] = (u32)y[i][e] & ((1u << 29) - 1);
                 yhi[i][e] = (u32)(y[i][e] >> 29);
+                ysum[i][e] = ylo[i][e] + yhi[i][e];
             }
     }
 #pragma unroll
     for (int jj = 0; jj < TGT; jj++) {
         const int j = min(j0 + jj, nd - 1);
-        const ModDev m = g.mods[K.dst_mod[j]];
+        const ModDev m = ld_mod(mods_c, K.dst_mod[j]);
         u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0, r0 = 0, r1 = 0;
+#if defined(LSA_BC_DIAG_NO_MATH)       // diagnostic build: the loads and the stores, no conversion arithmetic
         if (SPLIT) {
+            st2(dst + ((long long)g.rows.dst_row[j] << g.logn), xin[jj % NSMAX].x + v0, xin[jj % NSMAX].y + v1);
+            continue;
+        }
+#endif
+        if (SPLIT) {
+            // columns y0 w0, (y0 + y1)(w0 + w1), y1 w1: three multiply-accumulates per term (the middle column is recovered as
+            // cm - c0 - c2); 30-bit factors: up to 8 terms stay below 2^63, more take the four-product form
+            constexpr bool KARA = NSMAX <= 8;
             u64 c0[2] = {0, 0}, c1[2] = {0, 0}, c2[2] = {0, 0};
 #pragma unroll
             for (int i = 0; i < NSMAX; i++) {
                 if (EXACT || i < ns) {
-                    const u32 w0 = K.shat_lo[j][i], w1 = K.shat_hi[j][i];
+                    const u32 w0 = K.shat_lo[j][i], w1 = K.shat_hi[j][i], ws = K.shat_sum[j][i];
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         c0[e] += (u64)ylo[i][e] * w0;
-                        c1[e] += (u64)ylo[i][e] * w1;
-                        c1[e] += (u64)yhi[i][e] * w0;
                         c2[e] += (u64)yhi[i][e] * w1;
+                        if (KARA) {
+                            c1[e] += (u64)ysum[i][e] * ws;
+                        } else {
+                            c1[e] += (u64)ylo[i][e] * w1;
+                            c1[e] += (u64)yhi[i][e] * w0;
+                        }
                     }
                 }
             }
-            // sum = c0 + c1 * 2^29 + c2 * 2^58 < 16 * 2^116: (hi, lo), below p_j * 2^64
+            // sum = c0 + c1 * 2^29 + c2 * 2^58 (+ the output corrections, Montgomery form) as (hi, lo) below p_j * 2^64
             u64 hs[2], ls[2];
+            const u64 cr[2] = {(u64)(u32)v0 * K.corr_a[j] + K.corr_b[j], (u64)(u32)v1 * K.corr_a[j] + K.corr_b[j]};
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const u64 a = c0[e] + (c1[e] << 29);
+                const u64 mid = KARA ? c1[e] - c0[e] - c2[e] : c1[e];
+                const u64 a = c0[e] + (mid << 29);
                 const u64 b = a + (c2[e] << 58);
-                ls[e] = b;
-                hs[e] = (c1[e] >> 35) + (c2[e] >> 6) + (a < c0[e] ? 1 : 0) + (b < a ? 1 : 0);
+                const u64 d = b + cr[e];
+                ls[e] = d;
+                hs[e] = (mid >> 35) + (c2[e] >> 6) + (a < c0[e] ? 1 : 0) + (b < a ? 1 : 0) + (d < b ? 1 : 0);
             }
             r0 = csub(mont_redc_lazy(hs[0], ls[0], m.q, m.qinv), m.q);
             r1 = csub(mont_redc_lazy(hs[1], ls[1], m.q, m.qinv), m.q);
+#if defined(LSA_BC_DIAG_NO_STORE)      // diagnostic build: all the arithmetic, (almost) no store traffic
+            if (r0 == 0x123456789abcdefull) st2(dst + ((long long)g.rows.dst_row[j] << g.logn), r0, r1);
+#else
+            st2(dst + ((long long)g.rows.dst_row[j] << g.logn), r0, r1);
+#endif
+            continue;
         } else {
 #pragma unroll
         for (int i = 0; i < NSMAX; i++) {

@@ -56,6 +56,10 @@ struct BaseConvConsts {
     int split29;
     u32 shat_lo[LSA_BC_MAX_DST][LSA_BC_MAX_SRC];
     u32 shat_hi[LSA_BC_MAX_DST][LSA_BC_MAX_SRC];
+    u32 shat_sum[LSA_BC_MAX_DST][LSA_BC_MAX_SRC];      // lo + hi: the middle column as ONE product (y0 + y1)(w0 + w1) - y0 w0 - y1 w1
+    // the output corrections -v*S - [centred] floor(S/2), Montgomery form, as ONE addend v * corr_a + corr_b (< 17 * 2^58) of the
+    // 128-bit sum ahead of its single REDC: corr_a = (-S) * 2^64 mod p_j, corr_b = (-floor(S/2)) * 2^64 mod p_j or 0
+    u64 corr_a[LSA_BC_MAX_DST], corr_b[LSA_BC_MAX_DST];
 };
 
 struct BaseConvPlan {

@@ -89,6 +89,42 @@ template <bool COL> __global__ __launch_bounds__(256, 4) void k_tile(u64* dst, c
     }
 }
 
+// the launch order of the real passes: batch item fastest.  Workgroup b -> batch item b % batch, tile (b / batch) of that item;
+// items are `stride` words apart (the operator workspaces use strides that are multiples of 2^16 words = 512 KiB)
+template <bool COL> __global__ __launch_bounds__(256, 4) void k_tile_batch(u64* dst, const u64* src, int batch, long long stride) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x % batch;
+    const unsigned rt = blockIdx.x / batch;
+    const size_t limb = rt >> 4;
+    const int tile = rt & 15;
+    const u64* g = src + (long long)b * stride + (limb << 16);
+    u64* o = dst + (long long)b * stride + (limb << 16);
+    ulonglong2 v[8];
+    int xs[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int l = 2 * (tid + p * 256);
+        xs[p] = COL ? ((l >> 4) << 8) + (tile << 4) + (l & 15) : (tile << 12) + l;
+        v[p] = *reinterpret_cast<const ulonglong2*>(g + xs[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int l = 2 * (tid + p * 256);
+        lds[l + (l >> 4)] = v[p].x;
+        lds[l + 1 + ((l + 1) >> 4)] = v[p].y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int l = 2 * (tid + p * 256);
+        ulonglong2 w;
+        w.x = lds[l + (l >> 4)] + 1;
+        w.y = lds[l + 1 + ((l + 1) >> 4)] + 1;
+        *reinterpret_cast<ulonglong2*>(o + xs[p]) = w;
+    }
+}
+
 static float timed(void (*fn)(void*), void* ctx, int reps = 8) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -157,5 +193,37 @@ int main() {
     RUN("tile columns 128B, 3 wg/CU-limit, out of place", 2 * B, TILE(true, 3, c.b));
     RUN("tile columns 128B, 4 wg/CU-limit, out of place", 2 * B, TILE(true, 4, c.b));
     RUN("tile columns 128B, 4 wg/CU-limit, IN PLACE", 2 * B, TILE(true, 4, c.a));
+    // batch-fastest order, 64 items of `rows` limbs each, item stride = rows limbs (+ pad words)
+    {
+        const int batch = 64;
+        for (int rows : {26, 32, 68}) {
+            for (long long pad : {0LL, 512LL, 2080LL, 8192LL + 272}) {
+                const long long stride = ((long long)rows << 16) + pad;
+                if ((size_t)stride * batch > cx.n) continue;
+                const unsigned grid = (unsigned)(batch * rows * 16);
+                const double bytes = 2.0 * batch * rows * 65536 * 8;
+                for (int col = 0; col < 2; col++) {
+                    hipEvent_t e0, e1;
+                    CK(hipEventCreate(&e0));
+                    CK(hipEventCreate(&e1));
+                    auto go = [&]() {
+                        if (col) k_tile_batch<true><<<grid, 256, 40 * 1024 - 512, 0>>>(cx.a, cx.a, batch, stride);
+                        else k_tile_batch<false><<<grid, 256, 40 * 1024 - 512, 0>>>(cx.a, cx.a, batch, stride);
+                    };
+                    go();
+                    go();
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0, 0));
+                    for (int i = 0; i < 8; i++) go();
+                    CK(hipEventRecord(e1, 0));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    printf("batch-fastest in place, %s, %d limbs/item, pad %5lld words: %8.0f GB/s\n", col ? "columns 128B" : "contiguous  ", rows, pad, bytes / (ms / 8) / 1e6);
+                    fflush(stdout);
+                }
+            }
+        }
+    }
     return 0;
 }
