@@ -38,6 +38,7 @@ Context::Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_
     // of 512 / 1024 threads: half the HBM traffic, but one or two workgroups per CU and R limbs fill only R CUs --
     // launch_ntt picks per launch; LSA_NTT_WIDE=0 / 1 forces never / always.
     plan_wide = make_ntt_plan(logn, (logn == 13 || logn == 14) ? logn : LSA_NTT_TAU);
+    if (const char* e = std::getenv("LSA_NTT_FP_RAW")) fp_raw = e[0] != '0';
     if (const char* wide = std::getenv("LSA_NTT_WIDE")) wide_mode = wide[0] == '0' ? 0 : wide[0] == '1' ? 1 : 2;
     LSA_REQUIRE(plan.npass == 1 || plan.pass[1].mu <= plan.pass[1].tau, "ring degree too large for the NTT tile size");
 

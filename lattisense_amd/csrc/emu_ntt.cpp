@@ -51,11 +51,19 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
     a.row_step = 1;
     a.row_inner = row_inner;
     for (int i = 0; i < period; i++) a.mod_of[i] = mod_of[i];
+    // as launch_ntt: the grid covers the active rows only
+    int launch_rows = 0;
+    for (int r = 0; r < rows; r++)
+        if (mod_of[r % period] != LSA_ROW_SKIP) a.row_tbl[launch_rows++] = (unsigned short)r;
+    a.compact = 1;
+    a.rows = launch_rows;
     for (int step = 0; step < plan.npass; step++) {
         int k = inverse ? plan.npass - 1 - step : step;
         ntt_fill_pass(a, plan, T.logn, k, inverse);
+        a.fp_raw_out = plan.npass == 2 && step == 0;   // as launch_ntt sets them
+        a.fp_raw_in = plan.npass == 2 && step == 1;
         std::vector<u64> lds(lds_words(a.tau));
-        long long nblocks = (long long)batch * rows * (1 << (a.logn - a.tau));
+        long long nblocks = (long long)batch * launch_rows * (1 << (a.logn - a.tau));
         for (long long bid = 0; bid < nblocks; bid++) {
             NttBlockCtx bc = ntt_decode_block(a, bid);
             if (bc.mod == LSA_ROW_SKIP) continue;

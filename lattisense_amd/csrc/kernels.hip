@@ -57,7 +57,9 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
 // traffic of the two-pass plan, at one or two workgroups per CU.
 // TWL: the pass holds global stage 0 (strided first pass of a two-pass plan): its 2^mu twiddles are the same for every tile
 // of the limb and go through LDS -- one fetch per workgroup, issued with the tile loads, instead of one per sub-pass.
-template <bool FZ, int NT, bool TWL = false>
+// FZ: 0 plain, 1 fused prologue only (first pass of a two-pass fused transform), 2 fused epilogue only (its last pass), 3 both
+// (single-pass transforms).  Split so that a pass carries only the tail code and registers it can execute.
+template <int FZ, int NT, bool TWL = false>
 __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVE
     return;
 #endif
     LSA_STAMP(0);
-    ntt_phase_load<FZ, NT>(a, bc, tid, lds);
+    ntt_phase_load<(FZ & 1) != 0, NT>(a, bc, tid, lds);
     if (TWL && tid < (1 << a.mu)) {
         u64* tw_l = lds + lds_words(a.tau);
         if (bc.fp) tw_l[tid] = twp.x;
@@ -103,11 +105,11 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVE
     __syncthreads();
     LSA_STAMP(2);
 #if defined(LSA_NTT_DIAG_COPY_ONLY)   // diagnostic build: data movement of the pass structure without butterflies
-    ntt_phase_store<FZ, NT>(a, bc, tid, lds);
+    ntt_phase_store<(FZ & 2) != 0, NT>(a, bc, tid, lds);
     return;
 #endif
     ntt_butterfly_phases<NT, TWL>(a, bc, tid, lds);
-    ntt_phase_store<FZ, NT>(a, bc, tid, lds);
+    ntt_phase_store<(FZ & 2) != 0, NT>(a, bc, tid, lds);
     LSA_STAMP(7);
 #else
     // software-pipelined walk over consecutive tiles (same limb and tile index, different batch items: same twiddles)
@@ -131,39 +133,41 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVE
         if (have_nxt) ntt_phase_fetch<NT>(a, nxt, tid, stage);   // in flight during the butterflies below
         if (have) {
             ntt_butterfly_phases<NT>(a, bc, tid, lds);
-            ntt_phase_store<FZ, NT>(a, bc, tid, lds);
+            ntt_phase_store<(FZ & 2) != 0, NT>(a, bc, tid, lds);
         }
         __syncthreads();   // LDS is reused by the next tile
     }
 #endif
 }
 
-template <int NT>
-static void ntt_launch_pass(const NttPassArgs& a, bool fused, long long nblocks, size_t lds_bytes, hipStream_t s) {
-    LSA_REQUIRE((1 << a.tau) <= 2 * LSA_NTT_STAGE_PAIRS * NT, "ntt: tile larger than the staging registers");
-#if defined(LSA_NTT_TWL)
-    if (NT == 256 && a.s_lo == 0 && a.lambda != 0 && a.mu <= 8) {   // strided first pass of a two-pass plan: twiddles via LDS
-        const size_t bytes = lds_bytes + (2u << a.mu) * sizeof(u64);
-        if (fused) hipLaunchKernelGGL((k_ntt_pass<true, NT, true>), dim3((unsigned)nblocks), dim3(NT), bytes, s, a);
-        else hipLaunchKernelGGL((k_ntt_pass<false, NT, true>), dim3((unsigned)nblocks), dim3(NT), bytes, s, a);
-        LSA_HIP(hipGetLastError());
-        return;
-    }
-#endif
+template <int FZ, int NT>
+static void ntt_launch_variant(const NttPassArgs& a, long long nblocks, size_t lds_bytes, hipStream_t s) {
     if (lds_bytes > 65536) {   // whole-limb tiles: opt in to more than 64 KiB of dynamic LDS, once per kernel instance AND device
-        static std::atomic<unsigned long long> raised[2] = {{0}, {0}};   // bit d: done on device d (the attribute is per device)
+        static std::atomic<unsigned long long> raised{0};   // bit d: done on device d (the attribute is per device)
         int dev = 0;
         LSA_HIP(hipGetDevice(&dev));
         const unsigned long long bit = 1ull << (dev & 63);
-        if (!(raised[fused].load(std::memory_order_acquire) & bit)) {
-            const void* fn = fused ? reinterpret_cast<const void*>(&k_ntt_pass<true, NT>) : reinterpret_cast<const void*>(&k_ntt_pass<false, NT>);
-            LSA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised[fused].fetch_or(bit, std::memory_order_release);
+        if (!(raised.load(std::memory_order_acquire) & bit)) {
+            LSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FZ, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised.fetch_or(bit, std::memory_order_release);
         }
     }
-    if (fused) hipLaunchKernelGGL((k_ntt_pass<true, NT>), dim3((unsigned)nblocks), dim3(NT), lds_bytes, s, a);
-    else hipLaunchKernelGGL((k_ntt_pass<false, NT>), dim3((unsigned)nblocks), dim3(NT), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_ntt_pass<FZ, NT>), dim3((unsigned)nblocks), dim3(NT), lds_bytes, s, a);
     LSA_HIP(hipGetLastError());
+}
+
+template <int NT>
+static void ntt_launch_pass(const NttPassArgs& a, bool fused, long long nblocks, size_t lds_bytes, hipStream_t s) {
+    LSA_REQUIRE((1 << a.tau) <= 2 * LSA_NTT_STAGE_PAIRS * NT, "ntt: tile larger than the staging registers");
+    // which fused tail this pass can execute: the prologue lives in the pass that holds stage 0, the epilogue in the pass
+    // that reduces and stores the final values
+    const bool pro = fused && a.fz_pro && a.s_lo == 0, epi = fused && a.fz_epi && a.final_reduce;
+    switch ((pro ? 1 : 0) | (epi ? 2 : 0)) {
+        case 0: ntt_launch_variant<0, NT>(a, nblocks, lds_bytes, s); break;
+        case 1: ntt_launch_variant<1, NT>(a, nblocks, lds_bytes, s); break;
+        case 2: ntt_launch_variant<2, NT>(a, nblocks, lds_bytes, s); break;
+        default: ntt_launch_variant<3, NT>(a, nblocks, lds_bytes, s); break;
+    }
 }
 
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch_stride, int rows, const RowMap& rm,
@@ -217,6 +221,20 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
     }
     int active_rows = 0;
     for (int r = 0; r < rows; r++) active_rows += rm.mod_of[(rm.row0 + r * rm.row_step) % rm.period] != LSA_ROW_SKIP;
+    if (active_rows == 0) return;
+    // the grid covers the active rows only
+    int launch_rows = rows;
+    a.compact = 0;
+    if (active_rows <= LSA_MAX_PERIOD && rm.row0 + (rows - 1) * rm.row_step < 65536) {
+        a.compact = 1;
+        int k = 0;
+        for (int r = 0; r < rows; r++) {
+            const int row = rm.row0 + r * rm.row_step;
+            if (rm.mod_of[row % rm.period] != LSA_ROW_SKIP) a.row_tbl[k++] = (unsigned short)row;
+        }
+        launch_rows = active_rows;
+    }
+    a.rows = launch_rows;
     // Two-pass transforms: run both passes on a chunk of the batch that fits the 256 MiB Infinity Cache before moving
     // on, so the second pass reads what the first just wrote from the memory-side cache instead of HBM.
     // whole-limb single pass (N = 2^13 / 2^14) where it measured faster: launches that fill the chip at one (2^14) or two
@@ -255,11 +273,13 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         for (int step = 0; step < plan.npass; step++) {
             const int k = inverse ? plan.npass - 1 - step : step;
             ntt_fill_pass(a, plan, c.logn, k, inverse ? 1 : 0);
+            a.fp_raw_out = plan.npass == 2 && step == 0 && c.fp_raw;
+            a.fp_raw_in = plan.npass == 2 && step == 1 && c.fp_raw;
             a.src = (step == 0 ? src + (long long)b0 * src_stride : dst + (long long)b0 * dst_stride);
             a.src_stride = step == 0 ? src_stride : dst_stride;
             a.dst = dst + (long long)b0 * dst_stride;
             a.dst_stride = dst_stride;
-            a.total_tiles = (long long)nb * rows * (1 << (a.logn - a.tau));
+            a.total_tiles = (long long)nb * launch_rows * (1 << (a.logn - a.tau));
             const long long nblocks = (a.total_tiles + LSA_NTT_TILES_PER_WG - 1) / LSA_NTT_TILES_PER_WG;
             LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
             const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);

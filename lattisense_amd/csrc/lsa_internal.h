@@ -92,6 +92,7 @@ struct Context {
     double* d_scale_d = nullptr;
     int fp64_ntt = 1;               // use the FP64 butterfly engine for limbs with q < 2^47
     int tile_batch = 0;
+    int fp_raw = 1;                 // FP64-engine limbs cross between the two NTT passes as doubles (LSA_NTT_FP_RAW=0: canonical u64)
     int fuse_tails = 1;             // ModDown / rescale element-wise tails fused into the NTT load/store phases
     int dual_stream = 0;            // 1: overlap alternate tiles of an operator on an auxiliary stream (+5% throughput,
                                     // but per-kernel timings then include the co-running kernel; off for clean accounting)

@@ -57,6 +57,10 @@ struct NttPassArgs {
     const u64* scale;     // [nmod][2][2] inverse only: the same pairs for N^-1 and psiinv[1] * N^-1
     const double* twd;    // [nmod][N] the same twiddles as plain doubles (FP64 engine)
     const double* scaled; // [nmod][2]
+    // FP64-engine limbs of a two-pass transform travel between the passes as integer-valued doubles, |v| <= q/2 + 1 (the
+    // first pass stores the reduced value's bits, the second loads them as they are): no sign fix and no conversions at the
+    // hand-off -- 6 (forward) / 9 (inverse) of the ~94 double-precision operations a point costs per transform
+    int fp_raw_in, fp_raw_out;
     int logn, s_lo, mu, lambda, tau;
     int inverse;          // 0 forward, 1 inverse
     int apply_scale;      // inverse: this pass contains global stage 0 -> fold N^-1
@@ -64,6 +68,10 @@ struct NttPassArgs {
     int allow_fp64;       // 0 forces the integer engine for every limb
     int period;           // row r uses modulus mod_of[r % period]
     int row0, row_step;   // the launch's i-th row is row r = row0 + i * row_step of the batch item
+    int compact;          // 1: the grid covers only the ACTIVE rows; the launch's i-th row is row_tbl[i] (rows whose modulus is
+                          // LSA_ROW_SKIP get no workgroups at all: the digit's own limbs in the extension transform and the Q
+                          // limbs in the ModDown inverse were 19 % / 70 % of those grids, ~3 ns of dispatch each)
+    unsigned short row_tbl[LSA_MAX_PERIOD];
     int row_inner;        // workgroup order: 0 = (row, tile, batch), 1 = (tile, row, batch), batch fastest in both
     // ---- fused element-wise tails (rows of the transformed buffer are [poly][fz_limbs]):
     // epilogue of the LAST pass of a forward transform, replaces the plain store of the transformed value v:
@@ -105,15 +113,17 @@ LSA_HD NttBlockCtx ntt_decode_block(const NttPassArgs& a, long long bid) {
     int b = (int)(bid % a.batch);
     long long rt = bid / a.batch;
     int row;
+    int ri;   // index of the row within the launch
     if (a.row_inner) {
         // rows in the middle: consecutive batch-sized runs of workgroups walk over the launch's limbs at one tile position,
         // so the workgroups resident on a CU mix integer-engine (multiply-bound) and FP64-engine (traffic-bound) limbs
         c.tile = (int)(rt / a.rows);
-        row = a.row0 + (int)(rt % a.rows) * a.row_step;
+        ri = (int)(rt % a.rows);
     } else {
         c.tile = (int)(rt % tiles);
-        row = a.row0 + (int)(rt / tiles) * a.row_step;
+        ri = (int)(rt / tiles);
     }
+    row = a.compact ? (int)a.row_tbl[ri] : a.row0 + ri * a.row_step;
     c.base_src = (long long)b * a.src_stride + ((long long)row << a.logn);
     c.base_dst = (long long)b * a.dst_stride + ((long long)row << a.logn);
     c.mod = a.mod_of[row % a.period];
@@ -198,7 +208,7 @@ LSA_HD double fp_reduce(double x, double q, double qinv) { return __builtin_fma(
 #define LSA_NTT_HEAD_ROUNDS 2   // two-operand prologue: load rounds per tile (1 = all 16 operand pairs in flight at once)
 #endif
 struct NttLoadFix {   // per-block constants of the load-side conversions
-    bool head, add, fp, near;
+    bool head, add, fp, near, raw;
     u64 ql, h, hq;
     ModDev mi;
 };
@@ -211,7 +221,7 @@ LSA_HD u64 ntt_load_fix(const NttLoadFix& f, u64 v, u64 t) {
         const u64 lift = sub_mod(f.near ? csub(c, f.mi.q) : reduce_u64(c, f.mi), f.hq, f.mi.q);
         v = f.add ? add_mod(v, lift, f.mi.q) : lift;
     }
-    if (f.fp) v = d_to_bits(u52_to_double(v));  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact
+    if (f.fp && !f.raw) v = d_to_bits(u52_to_double(v));  // inputs of an FP64-engine limb are canonical or lazy (< 4q < 2^49): exact
     return v;
 }
 // FZ = false compiles the fused prologue out (plain launches: fewer live constants, smaller code)
@@ -224,6 +234,7 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
     f.head = FZ && a.fz_pro && a.s_lo == 0;   // fused rescale head: the tile is derived from the (coefficient-domain) last limb
     f.add = f.head && a.fz_pro == 2;
     f.fp = bc.fp != 0;
+    f.raw = f.fp && a.fp_raw_in;   // (never together with a fused prologue: that belongs to the first pass)
     f.mi = a.mods[bc.mod];
     f.ql = f.h = f.hq = 0;
     f.near = false;
@@ -335,13 +346,14 @@ LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 #define LSA_NTT_STORE_CHUNK 4
 #endif
 struct NttStoreFix {   // per-block constants of the store-side conversions
-    bool fp, final_reduce, tail, with_base, merged, lazy;
+    bool fp, final_reduce, tail, with_base, merged, lazy, raw;
     u64 q, qinv, k, k2;
     double qd, qinvd, kd, k2d;   // kd/k2d: the tail factors as plain doubles (FP64-engine limbs)
 };
 LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
     if (f.fp) {
         double r = fp_reduce(d_from_bits(v), f.qd, f.qinvd);   // |r| <= q/2 (+ rounding slack)
+        if (f.raw) return d_to_bits(r);   // first pass of a two-pass transform: the second pass's butterflies start from this
         if (f.tail) {   // the fused tail of an FP64-engine limb stays on the FP64 engine: exact, 6 operations per product
             const double ad = u52_to_double(va), bd = f.with_base ? u52_to_double(vb) : 0.0;
             if (f.merged) r = fp_modmul(fp_modmul(ad, f.kd, f.qd, f.qinvd) - r + bd, f.k2d, f.qd, f.qinvd);
@@ -394,6 +406,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     f.fp = bc.fp != 0;
     f.final_reduce = a.final_reduce != 0;
     f.lazy = !a.inverse && (md.q >> LSA_NTT_LAZY_BITS) == 0;
+    f.raw = f.fp && a.fp_raw_out;
     f.tail = FZ && a.fz_epi && a.final_reduce;
     f.q = md.q;
     f.qinv = md.qinv;

@@ -71,3 +71,20 @@ def test_fp64_engine_matches_oracle(emu, logn, tau):
     _check(emu, logn, tau, mods, fp64=1)
     _check(emu, logn, tau, mods, fp64=0)
     _check(emu, logn, tau, mods, fp64=3)   # the interleaved workgroup order of mixed-engine launches
+
+
+def test_skipped_rows_get_no_workgroups(emu):
+    """rows whose modulus is LSA_ROW_SKIP (0xFF) are left untouched and the grid is compacted to the active rows"""
+    B = params.CKKS_BOOTSTRAP_65536
+    mods = B["q"][:3]
+    n = 1 << 13
+    o = Oracle(n, mods, [], 0)
+    rng = np.random.default_rng(4)
+    rows, mod_of = 5, [0, 0xFF, 2, 0xFF, 1]
+    data = np.stack([np.stack([rng.integers(0, mods[m if m != 0xFF else 0], size=n, dtype=np.uint64) for m in mod_of]) for _ in range(2)])
+    got = data.copy()
+    run(emu, n, mods, got, rows, mod_of, 0, 12, 1)
+    for b in range(2):
+        for r, m in enumerate(mod_of):
+            want = data[b, r] if m == 0xFF else o.ntt(m, data[b, r])
+            assert np.array_equal(got[b, r], want), (b, r)
