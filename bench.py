@@ -467,16 +467,22 @@ def main():
                     "avg_launch_us": ntt["avg_launch_us"], "launches_per_step": ntt["launches_per_step"],
                     "sampling": "HIP event pair around one launch in %d (hash-picked), on the launch stream" % args.prof_stride}
 
-    # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed
-    # rocprofv3 --pmc passes of this same command (tools/profile.sh -> profiles/), matched on workload and batch.
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 wraps the process); they
+    # come from the committed --pmc passes of this same command (tools/profile.sh + tools/pmc_traffic.py -> profiles/rNN/),
+    # matched on workload, batch AND a hash of the kernel sources: a file collected on other kernels is not reported.
     if roofline:
         try:
             import glob
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_traffic import sources_hash
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_k_ntt_pass.json")))
             pmc = json.load(open(cands[-1])) if cands else None
             if pmc and pmc["workload"] == args.workload and pmc["batch"] == batch:
-                roofline["traffic"] = pmc["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = os.path.relpath(cands[-1], ROOT)
+                if pmc.get("kernel_sources_sha256") == sources_hash():
+                    roofline["traffic"] = pmc["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = os.path.relpath(cands[-1], ROOT)
+                else:
+                    roofline["traffic_source"] = "stale: %s was collected on other kernel sources" % os.path.relpath(cands[-1], ROOT)
                 roofline["algorithmic_bytes_per_launch"] = ntt["achieved_GBps"] * 1e9 * ntt["avg_launch_us"] * 1e-6
         except Exception:
             pass

@@ -14,3 +14,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REP
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --no-cpu-baseline "$@" > /dev/null 2> $OUT/pmc_write.err
 cd $REPO && python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# HBM traffic per launch (FETCH_SIZE / WRITE_SIZE) next to the algorithmic bytes -> gpurun_out/prof_<tag>/pmc_traffic_k_ntt_pass.json
+python3 tools/pmc_traffic.py $OUT $OUT > $OUT/traffic.txt 2>&1; cat $OUT/traffic.txt
