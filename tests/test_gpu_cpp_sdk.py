@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_cpp_fhe_task_gpu(tmp_path):
     from lattisense_amd import build
-    lib = build.build_native()
+    lib = build.LIB          # the library that shipped with the tree (the GPU box never rebuilds it)
+    assert os.path.exists(lib), "liblattisense_amd.so is not built: run __graft_entry__.build()"
     libdir = os.path.dirname(lib)
     exe = str(tmp_path / "test_fhe_task_gpu")
     tl = build.torch_lib_dir()
