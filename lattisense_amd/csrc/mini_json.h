@@ -1,5 +1,7 @@
 // mini_json.h — small JSON DOM reader for mega_ag.json / task_signature.json (objects keep insertion order).
 #pragma once
+#include <cerrno>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <fstream>
@@ -89,6 +91,15 @@ public:
 private:
     const std::string& t;
     size_t p = 0;
+    int depth = 0;
+    static constexpr int kMaxDepth = 256;  // task files nest 5 deep; the bound keeps a hostile file from exhausting the stack
+    struct Nest {
+        Parser& ps;
+        explicit Nest(Parser& q) : ps(q) {
+            if (++ps.depth > kMaxDepth) ps.fail("nesting too deep");
+        }
+        ~Nest() { ps.depth--; }
+    };
     [[noreturn]] void fail(const std::string& m) { throw std::runtime_error("json parse error at " + std::to_string(p) + ": " + m); }
     void ws() {
         while (p < t.size() && (t[p] == ' ' || t[p] == '\n' || t[p] == '\t' || t[p] == '\r')) p++;
@@ -97,8 +108,14 @@ private:
         ws();
         if (p >= t.size()) fail("unexpected end");
         char c = t[p];
-        if (c == '{') return object();
-        if (c == '[') return array();
+        if (c == '{') {
+            Nest n(*this);
+            return object();
+        }
+        if (c == '[') {
+            Nest n(*this);
+            return array();
+        }
         if (c == '"') {
             Value v;
             v.kind = Value::String;
@@ -135,17 +152,24 @@ private:
         if (st == p) fail("bad number");
         std::string tok = t.substr(st, p - st);
         Value v;
+        char* end = nullptr;
+        errno = 0;
         if (is_float) {
             v.kind = Value::Float;
-            v.f = strtod(tok.c_str(), nullptr);
+            v.f = strtod(tok.c_str(), &end);
         } else {
             v.kind = Value::Int;
             if (tok[0] == '-') {
-                v.i = strtoll(tok.c_str(), nullptr, 10);
+                v.i = strtoll(tok.c_str(), &end, 10);
             } else {
-                v.i = (int64_t)strtoull(tok.c_str(), nullptr, 10);
+                v.i = (int64_t)strtoull(tok.c_str(), &end, 10);
                 v.is_unsigned = true;
             }
+        }
+        bool overflow = errno == ERANGE && (!is_float || std::isinf(v.f));  // a float that underflows to 0 is fine
+        if (end != tok.c_str() + tok.size() || overflow) {
+            p = st;
+            fail("bad number '" + tok + "'");
         }
         return v;
     }

@@ -4,6 +4,7 @@
 #include "task_graph.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <queue>
 #include <stdexcept>
@@ -42,11 +43,31 @@ OperationType op_type_of(const std::string& s) {
 
 bool is_custom_json(const mjson::Value& v) { return v.contains("is_custom") && v["is_custom"].as_bool(); }
 
+const mjson::Value& member_of_kind(const mjson::Value& root, const char* key, mjson::Value::Kind kind) {
+    const mjson::Value& v = root[key];
+    if (v.kind != kind)
+        throw std::runtime_error(std::string("mega_ag.json: '") + key + "' is not " + (kind == mjson::Value::Array ? "an array" : "an object"));
+    return v;
+}
+
+// a node index: a non-negative integer (a float or a negative number is a damaged file, not an index to truncate)
+NodeIndex index_of(const mjson::Value& v) {
+    if (v.kind != mjson::Value::Int || (!v.is_unsigned && v.i < 0)) throw std::runtime_error("mega_ag.json: node index is not a non-negative integer");
+    return (NodeIndex)v.as_u64();
+}
+
+NodeIndex index_of(const std::string& key) {
+    if (key.empty() || key.size() > 19 || key.find_first_not_of("0123456789") != std::string::npos)
+        throw std::runtime_error("mega_ag.json: node key '" + key + "' is not a non-negative integer");
+    return (NodeIndex)std::stoull(key);
+}
+
 }  // namespace
 
 TaskGraph TaskGraph::load_for_gpu(const std::string& json_path) {
     TaskGraph g;
     g.parse(json_path);
+    g.validate_structure();
     if (!getenv("LSA_NO_GRAPH_FUSION")) {
         g.fuse_accumulations();
         g.fuse_mult_relin_rescale();
@@ -70,10 +91,10 @@ void TaskGraph::parse(const std::string& json_path) {
     else throw std::runtime_error("Unknown algorithm: " + algo_s);
     parameter = root["parameter"];
 
-    for (auto& kv : root["data"].obj) {
+    for (auto& kv : member_of_kind(root, "data", mjson::Value::Object).obj) {
         const mjson::Value& v = kv.second;
         DatumNode n;
-        n.index = std::stoull(kv.first);
+        n.index = index_of(kv.first);
         n.id = v["id"].as_string();
         const std::string& type_s = v["type"].as_string();
         if (is_custom_json(v)) {
@@ -83,8 +104,10 @@ void TaskGraph::parse(const std::string& json_path) {
             n.custom_prop = cp;
         } else {
             DatumNode::FheProperty fp;
-            fp.level = (int32_t)v["level"].as_int();
-            fp.degree = (int32_t)v["degree"].as_int();
+            const int64_t lvl = v["level"].as_int(), deg = v["degree"].as_int();
+            if (lvl != (int32_t)lvl || deg != (int32_t)deg) throw std::runtime_error("datum " + n.id + ": level / degree out of range");
+            fp.level = (int32_t)lvl;
+            fp.degree = (int32_t)deg;
             fp.is_ntt = v["is_ntt"].as_bool();
             fp.is_mform = v["is_mform"].as_bool();
             fp.sp_level = v.contains("sp_level") ? (int32_t)v["sp_level"].as_int() : -1;
@@ -104,10 +127,10 @@ void TaskGraph::parse(const std::string& json_path) {
         data.emplace(n.index, std::move(n));
     }
 
-    for (auto& kv : root["compute"].obj) {
+    for (auto& kv : member_of_kind(root, "compute", mjson::Value::Object).obj) {
         const mjson::Value& v = kv.second;
         ComputeNode c;
-        c.index = std::stoull(kv.first);
+        c.index = index_of(kv.first);
         c.id = v["id"].as_string();
         const std::string& type_s = v["type"].as_string();
         if (is_custom_json(v)) {
@@ -129,8 +152,13 @@ void TaskGraph::parse(const std::string& json_path) {
             }
             c.fhe_prop = fp;
         }
-        for (auto& e : v["inputs"].arr) c.input_nodes.push_back(&data.at(e.as_u64()));
-        for (auto& e : v["outputs"].arr) c.output_nodes.push_back(&data.at(e.as_u64()));
+        auto datum = [&](const mjson::Value& e) {
+            auto it = data.find(index_of(e));
+            if (it == data.end()) throw std::runtime_error("compute node " + c.id + " names datum " + std::to_string(index_of(e)) + ", which the graph does not have");
+            return &it->second;
+        };
+        for (auto& e : member_of_kind(v, "inputs", mjson::Value::Array).arr) c.input_nodes.push_back(datum(e));
+        for (auto& e : member_of_kind(v, "outputs", mjson::Value::Array).arr) c.output_nodes.push_back(datum(e));
         next_compute = std::max(next_compute, c.index + 1);
         computes.emplace(c.index, std::move(c));
     }
@@ -138,13 +166,67 @@ void TaskGraph::parse(const std::string& json_path) {
         for (auto* d : kv.second.input_nodes) d->successors.push_back(&kv.second);
         for (auto* d : kv.second.output_nodes) d->predecessors.push_back(&kv.second);
     }
-    for (auto& e : root["inputs"].arr) {
-        inputs.push_back(e.as_u64());
-        data.at(e.as_u64()).is_input = true;
+    auto terminal = [&](const mjson::Value& e, const char* what) -> DatumNode& {
+        auto it = data.find(index_of(e));
+        if (it == data.end()) throw std::runtime_error(std::string("task ") + what + " " + std::to_string(index_of(e)) + " is not a datum of the graph");
+        return it->second;
+    };
+    for (auto& e : member_of_kind(root, "inputs", mjson::Value::Array).arr) {
+        inputs.push_back(index_of(e));
+        terminal(e, "input").is_input = true;
     }
-    for (auto& e : root["outputs"].arr) {
-        outputs.push_back(e.as_u64());
-        data.at(e.as_u64()).is_output = true;
+    for (auto& e : member_of_kind(root, "outputs", mjson::Value::Array).arr) {
+        outputs.push_back(index_of(e));
+        terminal(e, "output").is_output = true;
+    }
+}
+
+// What every later stage indexes without looking (input_nodes[0], output_nodes[0], predecessors[0]): each compute node has
+// exactly one output (one std::any per executor call, mega_ag.h:63-66) and the operands its operator takes; each datum has
+// one producer, or none when it is a task input.  The reference relies on its frontend to emit nothing else
+// (frontend/custom_task.py); a task file is an input of this library, so it is checked here.
+void TaskGraph::validate_structure() const {
+    auto bad = [](const ComputeNode& c, const std::string& why) {
+        throw std::runtime_error("compute node " + c.id + " (" + std::to_string(c.index) + "): " + why);
+    };
+    for (auto& kv : computes) {
+        const ComputeNode& c = kv.second;
+        if (c.output_nodes.size() != 1) bad(c, "has " + std::to_string(c.output_nodes.size()) + " outputs, expected 1");
+        if (c.custom_prop) continue;   // a caller's executor defines its own operands
+        const size_t n = c.input_nodes.size();
+        size_t lo = 1, hi = 1;
+        switch (c.op()) {
+            case OperationType::ADD:
+            case OperationType::SUB:
+            case OperationType::MULTIPLY: hi = 2; break;
+            case OperationType::RELINEARIZE:
+            case OperationType::ROTATE_COL:
+            case OperationType::ROTATE_ROW: lo = hi = 2; break;
+            case OperationType::MAC_WO_PARTIAL_SUM:
+            case OperationType::MAC_W_PARTIAL_SUM: lo = 2, hi = SIZE_MAX; break;
+            case OperationType::BOOTSTRAP: lo = 5, hi = SIZE_MAX; break;
+            default: break;   // neg, rescale, drop_level: one operand
+        }
+        if (n < lo || n > hi) bad(c, "has " + std::to_string(n) + " inputs");
+        for (const DatumNode* d : c.input_nodes)
+            if (!d->fhe_prop) bad(c, "operand " + d->id + " is custom data");
+        if (c.input_nodes[0]->datum_type != TYPE_CIPHERTEXT) bad(c, "first operand " + c.input_nodes[0]->id + " is not a ciphertext");
+        if (!c.output_nodes[0]->fhe_prop || c.output_nodes[0]->datum_type != TYPE_CIPHERTEXT) bad(c, "result " + c.output_nodes[0]->id + " is not a ciphertext");
+        if (lo == 2 && hi == 2) {
+            const DataType k = c.input_nodes[1]->datum_type;
+            if (k != TYPE_RELIN_KEY && k != TYPE_GALOIS_KEY && k != TYPE_SWITCH_KEY) bad(c, "second operand " + c.input_nodes[1]->id + " is not a key");
+        }
+    }
+    const int64_t n_q = parameter.contains("q") ? (int64_t)parameter["q"].size() : INT32_MAX;
+    for (auto& kv : data) {
+        const DatumNode& d = kv.second;
+        if (d.fhe_prop && (d.fhe_prop->level < 0 || d.fhe_prop->level >= n_q || d.fhe_prop->degree < 0 || d.fhe_prop->degree > 2))
+            throw std::runtime_error("datum " + d.id + ": level " + std::to_string(d.fhe_prop->level) + " / degree " +
+                                     std::to_string(d.fhe_prop->degree) + " outside the parameter set");
+        if (d.predecessors.size() > 1) throw std::runtime_error("datum " + d.id + " is produced by " + std::to_string(d.predecessors.size()) + " compute nodes");
+        if (d.is_input && !d.predecessors.empty()) throw std::runtime_error("task input " + d.id + " is also produced by compute node " + d.predecessors[0]->id);
+        if (!d.is_input && d.predecessors.empty() && !d.successors.empty()) throw std::runtime_error("datum " + d.id + " is read but neither a task input nor produced");
+        if (d.is_output && !d.is_input && d.predecessors.empty()) throw std::runtime_error("task output " + d.id + " is never produced");
     }
 }
 

@@ -175,6 +175,7 @@ struct TaskGraph {
 
 private:
     void parse(const std::string& json_path);
+    void validate_structure() const;
     void fuse_accumulations();
     void fuse_mult_relin_rescale();
     void insert_bridges();
