@@ -48,20 +48,35 @@ Context::Context(int algo_, int n_, const u64* q, int nq_, const u64* p, int np_
         throw Error(LSA_ERR_NO_DEVICE, "no HIP device available: this library has no CPU fallback");
     LSA_REQUIRE(device >= 0 && device < ndev, "device index out of range");
     use_device();
-    const size_t tw_bytes = (size_t)nmod * n * sizeof(u64);
     LSA_HIP(hipMalloc((void**)&d_mods, nmod * sizeof(ModDev)));
-    LSA_HIP(hipMalloc((void**)&d_psi, 2 * tw_bytes));      // {w, Shoup quotient} pairs
-    LSA_HIP(hipMalloc((void**)&d_psiinv, 2 * tw_bytes));
     LSA_HIP(hipMalloc((void**)&d_scale, (size_t)nmod * 4 * sizeof(u64)));
-    LSA_HIP(hipMemcpy(d_mods, T.mods.data(), nmod * sizeof(ModDev), hipMemcpyHostToDevice));
-    LSA_HIP(hipMemcpy(d_psi, T.psi.data(), 2 * tw_bytes, hipMemcpyHostToDevice));
-    LSA_HIP(hipMemcpy(d_psiinv, T.psiinv.data(), 2 * tw_bytes, hipMemcpyHostToDevice));
-    LSA_HIP(hipMemcpy(d_scale, T.scale.data(), (size_t)nmod * 4 * sizeof(u64), hipMemcpyHostToDevice));
-    LSA_HIP(hipMalloc((void**)&d_psi_d, tw_bytes));
-    LSA_HIP(hipMalloc((void**)&d_psiinv_d, tw_bytes));
     LSA_HIP(hipMalloc((void**)&d_scale_d, (size_t)nmod * 2 * sizeof(double)));
-    LSA_HIP(hipMemcpy(d_psi_d, T.psi_d.data(), tw_bytes, hipMemcpyHostToDevice));
-    LSA_HIP(hipMemcpy(d_psiinv_d, T.psiinv_d.data(), tw_bytes, hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_mods, T.mods.data(), nmod * sizeof(ModDev), hipMemcpyHostToDevice));
+    LSA_HIP(hipMemcpy(d_scale, T.scale.data(), (size_t)nmod * 4 * sizeof(u64), hipMemcpyHostToDevice));
+    // twiddle tables in the order the plan's sub-passes read them (ntt_core.h, "twiddle table layout"); the whole-limb plan of
+    // N = 2^13 / 2^14 groups its stages differently and gets its own copies
+    auto upload = [&](const NttPlan& pl, u64** psi, u64** psiinv, double** psi_d, double** psiinv_d) {
+        const size_t tw_bytes = (size_t)nmod * n * sizeof(u64);
+        std::vector<u64> pi(T.psi.size()), pii(T.psiinv.size());
+        std::vector<double> pd(T.psi_d.size()), pdi(T.psiinv_d.size());
+        for (int m = 0; m < nmod; m++) {
+            const size_t o = (size_t)m * n;
+            ntt_permute_twiddles(pl, logn, T.psi.data() + 2 * o, pi.data() + 2 * o, 2, false);
+            ntt_permute_twiddles(pl, logn, T.psiinv.data() + 2 * o, pii.data() + 2 * o, 2, false);
+            ntt_permute_twiddles(pl, logn, T.psi_d.data() + o, pd.data() + o, 1, true);
+            ntt_permute_twiddles(pl, logn, T.psiinv_d.data() + o, pdi.data() + o, 1, true);
+        }
+        LSA_HIP(hipMalloc((void**)psi, 2 * tw_bytes));      // {w, Shoup quotient} pairs
+        LSA_HIP(hipMalloc((void**)psiinv, 2 * tw_bytes));
+        LSA_HIP(hipMalloc((void**)psi_d, tw_bytes));
+        LSA_HIP(hipMalloc((void**)psiinv_d, tw_bytes));
+        LSA_HIP(hipMemcpy(*psi, pi.data(), 2 * tw_bytes, hipMemcpyHostToDevice));
+        LSA_HIP(hipMemcpy(*psiinv, pii.data(), 2 * tw_bytes, hipMemcpyHostToDevice));
+        LSA_HIP(hipMemcpy(*psi_d, pd.data(), tw_bytes, hipMemcpyHostToDevice));
+        LSA_HIP(hipMemcpy(*psiinv_d, pdi.data(), tw_bytes, hipMemcpyHostToDevice));
+    };
+    upload(plan, &d_psi, &d_psiinv, &d_psi_d, &d_psiinv_d);
+    if (plan_wide.npass < plan.npass) upload(plan_wide, &d_psi_w, &d_psiinv_w, &d_psi_d_w, &d_psiinv_d_w);
     LSA_HIP(hipMemcpy(d_scale_d, T.scale_d.data(), (size_t)nmod * 2 * sizeof(double), hipMemcpyHostToDevice));
 }
 
@@ -74,6 +89,10 @@ Context::~Context() {
     (void)hipFree(d_scale);
     (void)hipFree(d_psi_d);
     (void)hipFree(d_psiinv_d);
+    (void)hipFree(d_psi_w);
+    (void)hipFree(d_psiinv_w);
+    (void)hipFree(d_psi_d_w);
+    (void)hipFree(d_psiinv_d_w);
     (void)hipFree(d_scale_d);
     (void)hipFree(ws);
     (void)hipFree(ws2);

@@ -1,6 +1,7 @@
 // emu_ntt.cpp — CPU replay of the NTT kernel's phase functions, one simulated thread at a time
 // (g++ -DLSA_EMULATE).  Debugging aid for the kernel's indexing; used only by tests/test_emulate_ntt.py.
 #define LSA_EMULATE 1
+#include <cstddef>
 #include <vector>
 #include "ntt_plan.h"
 #include "tables.h"
@@ -33,6 +34,14 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
     lsa::HostTables T;
     T.build(n, std::vector<u64>(moduli, moduli + nmod));
     NttPlan plan = make_ntt_plan(T.logn, tau_max);
+    // tables in the plan's order, as Context uploads them
+    std::vector<u64> tw_i(T.psi.size());
+    std::vector<double> tw_d(T.psi_d.size());
+    for (int m = 0; m < nmod; m++) {
+        const size_t o = (size_t)m * n;
+        ntt_permute_twiddles(plan, T.logn, (inverse ? T.psiinv : T.psi).data() + 2 * o, tw_i.data() + 2 * o, 2, false);
+        ntt_permute_twiddles(plan, T.logn, (inverse ? T.psiinv_d : T.psi_d).data() + o, tw_d.data() + o, 1, true);
+    }
     NttPassArgs a{};
     a.src = data;
     a.dst = data;
@@ -41,9 +50,9 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
     a.batch = batch;
     a.rows = rows;
     a.mods = T.mods.data();
-    a.tw = inverse ? T.psiinv.data() : T.psi.data();
+    a.tw = tw_i.data();
     a.scale = T.scale.data();
-    a.twd = inverse ? T.psiinv_d.data() : T.psi_d.data();
+    a.twd = tw_d.data();
     a.scaled = T.scale_d.data();
     a.allow_fp64 = allow_fp64;
     a.period = period;

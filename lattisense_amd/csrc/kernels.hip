@@ -10,7 +10,8 @@ static constexpr int TPB = 256;
 
 // ------------------------------------------------------------------------------------------------ K1/K2 NTT pass
 #ifndef LSA_NTT_WAVES
-#define LSA_NTT_WAVES 3   // min waves/SIMD the register allocator must allow (= co-resident 256-thread workgroups per CU)
+#define LSA_NTT_WAVES 4   // min waves/SIMD the register allocator must allow (= co-resident 256-thread workgroups per CU):
+                          // 4 = at most 128 VGPRs; the plain and epilogue-only variants fit without spilling
 #endif
 #ifndef LSA_NTT_TILES_PER_WG
 #define LSA_NTT_TILES_PER_WG 1   // >1: a workgroup walks this many consecutive tiles, prefetching tile k+1 during tile k
@@ -50,7 +51,7 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
 
 // FZ: the launch carries a fused prologue/epilogue (NttPassArgs::fz_*)
 #ifndef LSA_NTT_WAVES_FUSED
-#define LSA_NTT_WAVES_FUSED LSA_NTT_WAVES
+#define LSA_NTT_WAVES_FUSED 3   // variants with the two-operand prologue (FZ & 1): 3 workgroups per CU, up to 168 VGPRs
 #endif
 // NT: workgroup size = tile points / 16.  256 threads (4096-point tiles, 3-4 workgroups per CU) is the two-pass shape;
 // 512 / 1024 threads hold a whole N = 2^13 / 2^14 limb in LDS (69 / 136 KiB) and transform it in ONE pass: half the HBM
@@ -60,7 +61,7 @@ __device__ __forceinline__ void ntt_butterfly_phases(const NttPassArgs& a, const
 // FZ: 0 plain, 1 fused prologue only (first pass of a two-pass fused transform), 2 fused epilogue only (its last pass), 3 both
 // (single-pass transforms).  Split so that a pass carries only the tail code and registers it can execute.
 template <int FZ, int NT, bool TWL = false>
-__global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : FZ ? LSA_NTT_WAVES_FUSED : LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
+__global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : (FZ & 1) ? LSA_NTT_WAVES_FUSED : LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
 #if LSA_NTT_TILES_PER_WG == 1
@@ -183,9 +184,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
     a.batch = batch;
     a.rows = rows;
     a.mods = c.d_mods;
-    a.tw = inverse ? c.d_psiinv : c.d_psi;
     a.scale = c.d_scale;
-    a.twd = inverse ? c.d_psiinv_d : c.d_psi_d;
     a.diag = c.ntt_diag;
     a.scaled = c.d_scale_d;
     a.allow_fp64 = c.fp64_ntt;
@@ -251,6 +250,8 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         wide = !fz && (c.logn == 13 ? limbs >= 1024 : (all_fp && limbs >= 512));
     }
     const NttPlan& plan = wide ? c.plan_wide : c.plan;
+    a.tw = wide ? (inverse ? c.d_psiinv_w : c.d_psi_w) : (inverse ? c.d_psiinv : c.d_psi);
+    a.twd = wide ? (inverse ? c.d_psiinv_d_w : c.d_psi_d_w) : (inverse ? c.d_psiinv_d : c.d_psi_d);
     {   // launches that mix both butterfly engines interleave their limbs (+1.4 % hmult / +2.2 % rotate NTT rate, profiles/r01/ab_row_inner.log)
         bool any_fp = false, any_int = false;
         for (int r = 0; r < rows; r++) {

@@ -89,6 +89,10 @@ struct Context {
     u64* d_scale = nullptr;
     double* d_psi_d = nullptr;      // FP64-engine copies of the twiddle tables
     double* d_psiinv_d = nullptr;
+    u64* d_psi_w = nullptr;         // the same four tables in the order of plan_wide (N = 2^13 / 2^14 only)
+    u64* d_psiinv_w = nullptr;
+    double* d_psi_d_w = nullptr;
+    double* d_psiinv_d_w = nullptr;
     double* d_scale_d = nullptr;
     int fp64_ntt = 1;               // use the FP64 butterfly engine for limbs with q < 2^47
     int tile_batch = 0;

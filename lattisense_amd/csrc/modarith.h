@@ -98,6 +98,60 @@ LSA_HD u64 shoup_mul_lazy(u64 v, u64 w, u64 ws, u64 q);
 LSA_HD u64 sub64(u64 a, u64 b) { return a - b; }
 LSA_HD u64 csub(u64 a, u64 q) { return a >= q ? a - q : a; }
 LSA_HD u64 shoup_mul_lazy(u64 v, u64 w, u64 ws, u64 q) { return sub64(mul_lo64(w, v), mul_lo64(mulhi64(ws, v), q)); }
+
+// ---- the NTT butterfly's multiply, written for what the instructions cost on gfx950 (tools/probe_issue.hip, cycles per
+// wave64 instruction and SIMD): v_mad_u64_u32 5.2, v_mul_lo/hi_u32 4.5-4.9, v_lshl_add_u64 4.6, 32-bit add/logic 2.6, but
+// a flag-carried 64-bit add or subtract (v_add_co/v_addc pair) 7 and a 64-bit compare-select-subtract 18.4: the adds,
+// compares and register moves around the ten multiplies were 60 % of the exact form's 128 cycles per butterfly.
+//   * quotient from the three high partial products only (two v_mul_hi + one multiply-add): t' in [t-2, t], so the product
+//     lands in [0, 4q) instead of [0, 2q) -- the range the extra bits of a 64-bit word pay for (q < 2^61: 8q < 2^64);
+//   * w*v + t'*(2^64 - q) as ONE chain of multiply-adds (the low-word cross terms accumulate in a chain of their own whose
+//     upper word is never read), no separate subtract;
+//   * the conditional subtraction decided by the sign of a - 4q (v_lshl_add_u64 + one compare + two selects).
+// One v_mad_u64_u32 each; the carry-out operand is unused.
+LSA_HD u64 mad64(u32 a, u32 b, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return (u64)a * b + c;
+#endif
+}
+LSA_HD u64 mul64(u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "v"(b));
+    return d;
+#else
+    return (u64)a * b;
+#endif
+}
+LSA_HD u32 mulhi32(u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (u32)(((u64)a * b) >> 32);
+#endif
+}
+// w*v mod q in [0, 4q) for ANY 64-bit v; w < q with its quotient ws = floor(w * 2^64 / q), nq = 2^64 - q
+LSA_HD u64 shoup_mul_approx(u64 v, u64 w, u64 ws, u64 nq) {
+    const u32 vl = (u32)v, vh = (u32)(v >> 32), wl = (u32)w, wh = (u32)(w >> 32), sl = (u32)ws, sh = (u32)(ws >> 32);
+    const u64 t = mad64(vh, sh, (u64)mulhi32(vh, sl)) + mulhi32(vl, sh);
+    const u32 tl = (u32)t, th = (u32)(t >> 32), nl = (u32)nq, nh = (u32)(nq >> 32);
+    u64 p = mul64(vl, wh);   // low-word cross terms; the upper word of this chain is never read
+    p = mad64(vh, wl, p);
+    p = mad64(tl, nh, p);
+    p = mad64(th, nl, p);
+    u64 r = mul64(vl, wl);
+    r = mad64(tl, nl, r);
+    return r + ((u64)(u32)p << 32);
+}
+// a in [0, 2m), m < 2^63: a - m if a >= m (nm = 2^64 - m)
+LSA_HD u64 csub_sign(u64 a, u64 nm) {
+    const u64 d = a + nm;
+    return (int)(u32)(d >> 32) < 0 ? a : d;
+}
 // a*b*2^-64 mod q in [0,q)
 LSA_HD u64 mont_mul(u64 a, u64 b, u64 q, u64 qinv) { return csub(mont_mul_lazy(a, b, q, qinv), q); }
 // plain a*b mod q for a,b in [0,q): two REDCs (a*b*R^-1, then *R^2*R^-1)

@@ -20,7 +20,9 @@
 //
 // Two butterfly engines, chosen per workgroup from the limb's modulus (results are the same canonical residues):
 //   INT  (any q < 2^61): Shoup/Harvey butterflies on v_mad_u64_u32 chains -- every twiddle w is stored with its quotient
-//         w' = floor(w*2^64/q), w*v mod q = w*v - mulhi(w', v)*q in [0,2q) -- lazy values in [0,4q);
+//         w' = floor(w*2^64/q); w*v mod q = w*v + t*(2^64-q) with t the quotient estimated from the three high partial
+//         products of w'*v, in [0,4q) -- lazy values in [0,8q) forward / [0,4q) inverse (modarith.h, shoup_mul_approx;
+//         -DLSA_NTT_EXACT_BFLY builds Harvey's exact-quotient [0,4q) form for A/B);
 //   FP64 (q < 2^47, i.e. most CKKS chain primes): every butterfly is 6 double-precision ops
 //         h = v*w ; l = fma(v,w,-h) ; c = rndne(h/q) ; d = fma(-c,q,h) ; t = d + l     (all exact, |t| < 1.1 q)
 //     — ~9 VALU issue slots per butterfly against ~30 plus VCC hazards on the integer engine (both the 32-bit integer
@@ -37,9 +39,15 @@
 #define LSA_NTT_THREADS 256
 #endif
 #define LSA_MAX_PERIOD 192
+#if defined(LSA_EMULATE)
+#include <cstdio>
+#include <cstdlib>
+#define LSA_EMU_CHECK(c) do { if (!(c)) { std::fprintf(stderr, "ntt replay: range invariant violated: %s (%s:%d)\n", #c, __FILE__, __LINE__); std::abort(); } } while (0)
+#else
+#define LSA_EMU_CHECK(c) do { } while (0)
+#endif
 #define LSA_ROW_SKIP 0xFF
 #define LSA_FP64_MAX_BITS 47
-#define LSA_NTT_LAZY_BITS 58   // integer engine: moduli below 2^58 run their forward transforms without per-butterfly reduction
 #ifndef LSA_NTT_MAX_RHO
 #define LSA_NTT_MAX_RHO 4   // largest radix exponent of a sub-pass (2^rho points per thread in VGPRs)
 #endif
@@ -96,6 +104,77 @@ struct NttPassArgs {
 
 LSA_HD int lds_addr(int l) { return l + (l >> 4); }
 LSA_HD int lds_words(int tau) { return (1 << tau) + (1 << (tau - 4)) + 16; }
+
+// ---- twiddle table layout.  Stage s owns the 2^s entries [2^s, 2^(s+1)) of a limb's table; a butterfly group G of a
+// radix-2^rho sub-pass uses, at its j-th stage, the 2^j entries of natural index (G << j) + k, k < 2^j.  In natural order a
+// wave's lanes (consecutive G) read entries 2^j apart: at j = 3 every lane touches its own 128-byte line, 64 lines per load
+// instruction, 680 line visits per wave and sub-pass on the integer engine -- 3..6 times what the tile's own data costs the
+// address unit.  The tables are therefore stored "k-major" per stage, for the j that stage has in the plan the table is
+// built for (ntt_plan.h): position (k << (s - j)) + G for the integer engine's 16-byte {w, w'} pairs -- a load instruction
+// of the wave reads 1 KiB contiguous -- and, for the FP64 engine's 8-byte entries, two k side by side:
+// ((k >> 1) << (s - j + 1)) + 2 G + (k & 1), again one 16-byte load per lane.
+// -DLSA_NTT_TW_NATURAL keeps the natural order (A/B builds).
+// position = (wave-uniform part, from s, j, k) + (per-lane part, from G): the kernel adds the first to the table's scalar
+// base and keeps the second as the load's 32-bit vector offset
+LSA_HD long long ntt_tw_u_int(int s, int j, int k) {
+#if defined(LSA_NTT_TW_NATURAL)
+    return k;
+#else
+    return (long long)k << (s - j);
+#endif
+}
+LSA_HD unsigned ntt_tw_v_int(int j, unsigned G) {
+#if defined(LSA_NTT_TW_NATURAL)
+    return G << j;
+#else
+    return G;
+#endif
+}
+LSA_HD long long ntt_tw_u_fp(int s, int j, int k) {
+#if defined(LSA_NTT_TW_NATURAL)
+    return k;
+#else
+    return j == 0 ? 0 : ((long long)(k >> 1) << (s - j + 1)) + (k & 1);
+#endif
+}
+LSA_HD unsigned ntt_tw_v_fp(int j, unsigned G) {
+#if defined(LSA_NTT_TW_NATURAL)
+    return G << j;
+#else
+    return j == 0 ? G : 2 * G;
+#endif
+}
+LSA_HD long long ntt_tw_pos_int(int s, int j, long long G, int k) { return ntt_tw_u_int(s, j, k) + ntt_tw_v_int(j, (unsigned)G); }
+LSA_HD long long ntt_tw_pos_fp(int s, int j, long long G, int k) { return ntt_tw_u_fp(s, j, k) + ntt_tw_v_fp(j, (unsigned)G); }
+LSA_HD void ntt_load_pair(const u64* p, u64& x, u64& y) {   // 16-byte aligned
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p);
+    x = v.x;
+    y = v.y;
+#else
+    x = p[0];
+    y = p[1];
+#endif
+}
+// the 2^j FP64-engine twiddles of stage s for butterfly group G (tws = the stage's first entry)
+LSA_HD void ntt_load_tw_fp(const double* tws, int s, int j, unsigned G, double* w) {
+    const unsigned gv = ntt_tw_v_fp(j, G);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LSA_NTT_TW_NATURAL)
+    if (j == 0) {
+        w[0] = tws[gv];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < (1 << j); k += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(tws + ntt_tw_u_fp(s, j, k) + gv);
+        w[k] = v.x;
+        w[k + 1] = v.y;
+    }
+#else
+#pragma unroll
+    for (int k = 0; k < (1 << j); k++) w[k] = (tws + ntt_tw_u_fp(s, j, k))[gv];
+#endif
+}
 
 struct NttBlockCtx {
     long long base_src;   // element offset of this (batch,row) limb in src
@@ -346,7 +425,7 @@ LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 #define LSA_NTT_STORE_CHUNK 4
 #endif
 struct NttStoreFix {   // per-block constants of the store-side conversions
-    bool fp, final_reduce, tail, with_base, merged, lazy, raw;
+    bool fp, final_reduce, tail, with_base, merged, raw;
     u64 q, qinv, k, k2;
     double qd, qinvd, kd, k2d;   // kd/k2d: the tail factors as plain doubles (FP64-engine limbs)
 };
@@ -364,13 +443,8 @@ LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
         return double_to_u52(r);
     }
     if (f.final_reduce) {
-#if defined(LSA_NTT_LAZY)
-        if (f.lazy) {   // forward transform of a lazy limb: values below 44q
-            v = csub(v, 32 * f.q);
-            v = csub(v, 16 * f.q);
-            v = csub(v, 8 * f.q);
-            v = csub(v, 4 * f.q);
-        }
+#if !defined(LSA_NTT_EXACT_BFLY)
+        v = csub(v, 4 * f.q);   // forward transforms end below 8q
 #endif
         v = csub(csub(v, 2 * f.q), f.q);
     }
@@ -405,7 +479,6 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     NttStoreFix f;
     f.fp = bc.fp != 0;
     f.final_reduce = a.final_reduce != 0;
-    f.lazy = !a.inverse && (md.q >> LSA_NTT_LAZY_BITS) == 0;
     f.raw = f.fp && a.fp_raw_out;
     f.tail = FZ && a.fz_epi && a.final_reduce;
     f.q = md.q;
@@ -472,15 +545,14 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
 // LIN: the padded LDS addresses of a group's 2^RHO elements are an arithmetic progression (beta0 == 0 or >= 4), so one
 // add per element replaces the shift/add padding arithmetic.
 // TWL: the twiddles come from the block's LDS copy (bc.tw_l, indexed like the limb's global slice) instead of global memory
-// LAZY (forward transforms of limbs with q < 2^58): the butterfly skips the conditional subtraction on its sum path.  Shoup's
-// product accepts any 64-bit operand and returns [0,2q), so both outputs grow by at most 2q per stage: from inputs below 4q a
-// whole transform of log N <= 20 stages stays below (4 + 2 log N) q <= 44q < 2^64, and the one reduction happens in the
-// final store (ntt_store_fix) -- 6 conditional subtractions per point per transform instead of one per butterfly.
-template <int RHO, bool LIN, int NT, bool TWL = false, bool LAZY = false>
+template <int RHO, bool LIN, int NT, bool TWL = false>
 LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const ModDev md = a.mods[bc.mod];
     const u64 q = md.q, q2 = 2 * md.q;
+#if !defined(LSA_NTT_EXACT_BFLY)
+    const u64 q4 = 4 * md.q, nq = 0 - md.q, nq4 = 0 - q4;
+#endif
     const u64* tw = TWL ? bc.tw_l : a.tw + (((long long)bc.mod << a.logn) << 1);   // {w, ws} pairs
     const int beta0 = a.lambda + a.mu - sig0 - RHO;  // lowest active bit of this sub-pass in l
     const int ngroups = 1 << (a.tau - RHO);
@@ -502,19 +574,31 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
             for (int j = 0; j < RHO; j++) {
                 const int half = E >> (j + 1);
                 const int s = a.s_lo + sig0 + j;
-                const u64* twj = tw + 2 * ((1 << s) + ((long long)G << j));
+                const u64* tws = tw + 2 * (1LL << s);
+                u64 w[E / 2], ws[E / 2];   // this stage's 2^j twiddle pairs, one 16-byte load each
+#pragma unroll
+                for (int k = 0; k < (1 << j); k++) ntt_load_pair(tws + 2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, (unsigned)G), w[k], ws[k]);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
-                        const int ti = 2 * (e >> (RHO - j));
-                        u64 U = LAZY ? v[e] : csub(v[e], q2);
+                        const int k = e >> (RHO - j);
 #if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)   // diagnostic build: constant twiddle (wrong results, same arithmetic)
-                        u64 T = shoup_mul_lazy(v[e + half], (u64)(G + ti + 3), (u64)(G + ti + 5) << 40, q);
+                        const u64 wk = (u64)(G + 2 * k + 3), wsk = (u64)(G + 2 * k + 5) << 40;
 #else
-                        u64 T = shoup_mul_lazy(v[e + half], twj[ti], twj[ti + 1], q);
+                        const u64 wk = w[k], wsk = ws[k];
 #endif
+#if defined(LSA_NTT_EXACT_BFLY)   // Harvey's form: values in [0, 4q), exact quotient
+                        u64 U = csub(v[e], q2);
+                        u64 T = shoup_mul_lazy(v[e + half], wk, wsk, q);
                         v[e] = U + T;
                         v[e + half] = sub64(U + q2, T);
+#else                             // values in [0, 8q), product in [0, 4q) (modarith.h, shoup_mul_approx)
+                        u64 U = csub_sign(v[e], nq4);
+                        u64 T = shoup_mul_approx(v[e + half], wk, wsk, nq);
+                        LSA_EMU_CHECK(v[e] < 2 * q4 && U < q4 && T < q4);   // the range invariants, checked by the CPU replay
+                        v[e] = U + T;
+                        v[e + half] = sub64(U + q4, T);
+#endif
                     }
                 }
             }
@@ -523,26 +607,41 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
             for (int j = RHO - 1; j >= 0; j--) {
                 const int half = E >> (j + 1);
                 const int s = a.s_lo + sig0 + j;
-                const u64* twj = tw + 2 * ((1 << s) + ((long long)G << j));
                 if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
 #pragma unroll
                     for (int e = 0; e < half; e++) {
-                        u64 U = v[e], V = v[e + half];   // both in [0,2q)
+                        u64 U = v[e], V = v[e + half];   // both in [0,2q) (exact form) / [0,4q); the exact product lands in [0,2q)
                         v[e] = shoup_mul_lazy(U + V, sc0, sc0s, q);
+#if defined(LSA_NTT_EXACT_BFLY)
                         v[e + half] = shoup_mul_lazy(sub64(U + q2, V), sc1, sc1s, q);
+#else
+                        v[e + half] = shoup_mul_lazy(sub64(U + q4, V), sc1, sc1s, q);
+#endif
                     }
                     continue;
                 }
+                const u64* tws = tw + 2 * (1LL << s);
+                u64 w[E / 2], ws[E / 2];
+#pragma unroll
+                for (int k = 0; k < (1 << j); k++) ntt_load_pair(tws + 2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, (unsigned)G), w[k], ws[k]);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
-                        const int ti = 2 * (e >> (RHO - j));
-                        u64 U = v[e], V = v[e + half];   // both in [0,2q)
-                        v[e] = csub(U + V, q2);
+                        const int k = e >> (RHO - j);
+                        u64 U = v[e], V = v[e + half];
 #if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)
-                        v[e + half] = shoup_mul_lazy(sub64(U + q2, V), (u64)(G + ti + 3), (u64)(G + ti + 5) << 40, q);
+                        const u64 wk = (u64)(G + 2 * k + 3), wsk = (u64)(G + 2 * k + 5) << 40;
 #else
-                        v[e + half] = shoup_mul_lazy(sub64(U + q2, V), twj[ti], twj[ti + 1], q);
+                        const u64 wk = w[k], wsk = ws[k];
+#endif
+#if defined(LSA_NTT_EXACT_BFLY)   // both in [0,2q)
+                        v[e] = csub(U + V, q2);
+                        v[e + half] = shoup_mul_lazy(sub64(U + q2, V), wk, wsk, q);
+#else                             // both in [0,4q)
+                        LSA_EMU_CHECK(U < q4 && V < q4);
+                        v[e] = csub_sign(U + V, nq4);
+                        v[e + half] = shoup_mul_approx(sub64(U + q4, V), wk, wsk, nq);
+                        LSA_EMU_CHECK(v[e] < q4 && v[e + half] < q4);
 #endif
                     }
                 }
@@ -577,14 +676,15 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
             for (int j = 0; j < RHO; j++) {
                 const int half = E >> (j + 1);
                 const int s = a.s_lo + sig0 + j;
-                const double* twj = tw + (1 << s) + ((long long)G << j);
+                double w[E / 2];   // this stage's 2^j twiddles: one 8-byte (j = 0) or 2^(j-1) 16-byte loads
+                ntt_load_tw_fp(tw + (1LL << s), s, j, (unsigned)G, w);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
 #if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)   // diagnostic build: constant twiddle (wrong results, same arithmetic)
                         const double T = fp_modmul(v[e + half], (double)(G + j + 3), q, qinv);
 #else
-                        const double T = fp_modmul(v[e + half], twj[e >> (RHO - j)], q, qinv);
+                        const double T = fp_modmul(v[e + half], w[e >> (RHO - j)], q, qinv);
 #endif
                         const double U = v[e];
                         v[e] = U + T;          // |.| grows by < 1.1q per stage: <= 10.9q < 2^51 over a 9-stage pass
@@ -601,7 +701,6 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
             for (int j = RHO - 1; j >= 0; j--) {
                 const int half = E >> (j + 1);
                 const int s = a.s_lo + sig0 + j;
-                const double* twj = tw + (1 << s) + ((long long)G << j);
                 if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
 #pragma unroll
                     for (int e = 0; e < half; e++) {
@@ -611,12 +710,14 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
                     }
                     continue;
                 }
+                double w[E / 2];
+                ntt_load_tw_fp(tw + (1LL << s), s, j, (unsigned)G, w);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     if ((e & half) == 0) {
                         const double U = v[e], V = v[e + half];
                         v[e] = U + V;   // sums at most double per stage: < 16 * 1.1q inside a sub-pass
-                        v[e + half] = fp_modmul(U - V, twj[e >> (RHO - j)], q, qinv);
+                        v[e + half] = fp_modmul(U - V, w[e >> (RHO - j)], q, qinv);
                     }
                 }
             }
@@ -660,17 +761,6 @@ LSA_HD void ntt_phase_sub_sel(const NttPassArgs& a, const NttBlockCtx& bc, int t
         }
         return;
     }
-#if defined(LSA_NTT_LAZY)
-    if (!a.inverse && (a.mods[bc.mod].q >> LSA_NTT_LAZY_BITS) == 0) {
-        switch (rho) {
-            case 1: ntt_phase_sub<1, LIN, NT, TWL, true>(a, bc, tid, lds, sig0); break;
-            case 2: ntt_phase_sub<2, LIN, NT, TWL, true>(a, bc, tid, lds, sig0); break;
-            case 3: ntt_phase_sub<3, LIN, NT, TWL, true>(a, bc, tid, lds, sig0); break;
-            default: ntt_phase_sub<4, LIN, NT, TWL, true>(a, bc, tid, lds, sig0); break;
-        }
-        return;
-    }
-#endif
     switch (rho) {
         case 1: ntt_phase_sub<1, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;
         case 2: ntt_phase_sub<2, LIN, NT, TWL>(a, bc, tid, lds, sig0); break;

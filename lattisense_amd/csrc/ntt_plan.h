@@ -39,3 +39,34 @@ inline void ntt_fill_pass(NttPassArgs& a, const NttPlan& plan, int logn, int k, 
     a.apply_scale = inverse && s.s_lo == 0;
     a.final_reduce = inverse ? (k == 0) : (k == plan.npass - 1);
 }
+
+// j of every stage under `plan`: its position inside the radix group (sub-pass) that executes it -- what the twiddle
+// tables' per-stage order is keyed on (ntt_core.h, "twiddle table layout")
+inline void ntt_plan_stage_j(const NttPlan& plan, int logn, unsigned char* jl /*[logn]*/) {
+    for (int k = 0; k < plan.npass; k++) {
+        int rho[4];
+        const int np = ntt_split(plan.pass[k].mu, rho);
+        int s = plan.pass[k].s_lo;
+        for (int i = 0; i < np; i++)
+            for (int j = 0; j < rho[i]; j++) jl[s++] = (unsigned char)j;
+    }
+    (void)logn;
+}
+
+// natural-order table of one limb (entry x = the twiddle of merged index x, `words` u64/double words per entry) -> the
+// layout the kernel reads under `plan`; entry 0 is unused in both
+template <class T>
+inline void ntt_permute_twiddles(const NttPlan& plan, int logn, const T* nat, T* out, int words, bool fp) {
+    unsigned char jl[32] = {0};
+    ntt_plan_stage_j(plan, logn, jl);
+    for (int w = 0; w < words; w++) out[w] = nat[w];
+    for (int s = 0; s < logn; s++) {
+        const int j = jl[s];
+        for (long long i = 0; i < (1LL << s); i++) {
+            const long long G = i >> j;
+            const int k = (int)(i & ((1 << j) - 1));
+            const long long pos = (1LL << s) + (fp ? ntt_tw_pos_fp(s, j, G, k) : ntt_tw_pos_int(s, j, G, k));
+            for (int w = 0; w < words; w++) out[pos * words + w] = nat[((1LL << s) + i) * words + w];
+        }
+    }
+}

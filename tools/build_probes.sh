@@ -3,6 +3,6 @@
 set -e
 cd "$(dirname "$0")"
 mkdir -p bin
-for f in probe_hbm probe_pipe; do
+for f in probe_hbm probe_pipe probe_bfly probe_issue; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o bin/$f $f.hip
 done
