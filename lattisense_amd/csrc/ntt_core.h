@@ -444,9 +444,11 @@ LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
     }
     if (f.final_reduce) {
 #if !defined(LSA_NTT_EXACT_BFLY)
-        v = csub(v, 4 * f.q);   // forward transforms end below 8q
-#endif
+        v = csub_sign(v, 0 - 4 * f.q);   // forward transforms end below 8q
+        v = csub_sign(csub_sign(v, 0 - 2 * f.q), 0 - f.q);
+#else
         v = csub(csub(v, 2 * f.q), f.q);
+#endif
     }
     if (f.tail) {   // fused tail: the transformed value is consumed here and never stored
         if (f.merged) {
