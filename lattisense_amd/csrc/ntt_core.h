@@ -14,7 +14,11 @@
 //     crosses LDS once per 4 stages instead of once per stage;
 //   * all global accesses are 16 B/lane and contiguous per wave (pass A gathers >=128 B column segments);
 //   * LDS layout pads one 8-byte word per 16 so that both the stride-16 and the unit-stride sub-passes are
-//     conflict-free for ds_read_b64/ds_write_b64 (bank = (addr/4) mod 64, lane groups of 32);
+//     conflict-free for ds_read_b64/ds_write_b64 (bank = (addr/4) mod 64, lane groups of 32).  The stride-256 sub-pass of a
+//     first pass (consecutive words per lane: 32 lanes span 34 padded words) and the pair accesses of the load / store phases
+//     pay one extra cycle per 32 lanes: SQ_LDS_BANK_CONFLICT is 9 % of the LDS-active cycles of a first pass, 0 of a second
+//     (profiles/r02/hmult_b256_rocprofv3_summary.txt); a padding that serves those patterns breaks the other two, and the
+//     LDS is 2.6 % of the kernel's waits;
 //   * blockIdx -> (limb, tile, batch) with batch fastest: co-resident workgroups share one prime's twiddle slice, which
 //     therefore stays in L1/L2 (twiddles are excluded from the algorithmic byte count for exactly that reason).
 //
