@@ -291,12 +291,22 @@ LSA_HD double fp_reduce(double x, double q, double qinv) { return __builtin_fma(
 #define LSA_NTT_HEAD_ROUNDS 2   // two-operand prologue: load rounds per tile (1 = all 16 operand pairs in flight at once)
 #endif
 struct NttLoadFix {   // per-block constants of the load-side conversions
-    bool head, add, fp, near, raw;
+    bool head, add, fp, near, raw, fp_lift;
     u64 ql, h, hq;
+    double hd, qld;
     ModDev mi;
 };
 // v: the tile's own element; t: the last limb's element at the same position (head modes only)
 LSA_HD u64 ntt_load_fix(const NttLoadFix& f, u64 v, u64 t) {
+    if (f.fp_lift) {
+        // FP64-engine limb, q_l below 2^48: the engine takes any integer-valued double of small magnitude that is congruent
+        // to the input, so the centred remainder of the last limb (t if t <= h, else t - q_l) is used as it is -- no
+        // reduction modulo this limb's prime, 9 double-precision / select operations instead of four 64-bit modular ones.
+        // |in| < q + q_l / 2 < 2^48.6; a pass adds at most 1.1 q per stage: far below the engine's 2^51.
+        const double td = u52_to_double(t);
+        const double r = td > f.hd ? td - f.qld : td;
+        return d_to_bits(f.add ? u52_to_double(v) + r : r);
+    }
     if (f.head) {
         const u64 c = add_mod(t, f.h, f.ql);   // centred remainder + h, in [0, q_l)
         // chain primes are within a factor two of each other almost always: one conditional subtraction then replaces
@@ -320,7 +330,8 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
     f.raw = f.fp && a.fp_raw_in;   // (never together with a fused prologue: that belongs to the first pass)
     f.mi = a.mods[bc.mod];
     f.ql = f.h = f.hq = 0;
-    f.near = false;
+    f.hd = f.qld = 0.0;
+    f.near = f.fp_lift = false;
     if (f.head) {
         gl = a.fz_last + (long long)bc.b * a.fz_last_stride + ((long long)(bc.row / a.fz_limbs) * a.fz_last_rpp << a.logn);
         if (!f.add) g = gl;
@@ -328,6 +339,9 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
         f.h = (f.ql - 1) >> 1;
         f.hq = reduce_u64(f.h, f.mi);
         f.near = f.ql <= 2 * f.mi.q;
+        f.fp_lift = f.fp && (f.ql >> 48) == 0;
+        f.hd = (double)f.h;
+        f.qld = (double)f.ql;
     }
     const NttTileMap tm = ntt_tile_map(a, bc.tile);
     if (half == LSA_NTT_STAGE_PAIRS * NT && !f.add) {
@@ -362,10 +376,8 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
 #pragma unroll
             for (int p = 0; p < CH; p++) {
                 const int x = ntt_tile_index(tm, 2 * (tid + (p0 + p) * NT));
-                st[2 * p] = g[x];
-                st[2 * p + 1] = g[x + 1];
-                sl[2 * p] = gl[x];
-                sl[2 * p + 1] = gl[x + 1];
+                ntt_load_pair(g + x, st[2 * p], st[2 * p + 1]);
+                ntt_load_pair(gl + x, sl[2 * p], sl[2 * p + 1]);
             }
 #pragma unroll
             for (int p = 0; p < CH; p++) {
