@@ -776,11 +776,17 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const u64 mid = KARA ? c1[e] - c0[e] - c2[e] : c1[e];
+#if defined(LSA_BC_CARRY_COMPARES)   // A/B: carries recovered by 64-bit compares (18 cycles each on gfx950, tools/probe_issue.hip)
                 const u64 a = c0[e] + (mid << 29);
                 const u64 b = a + (c2[e] << 58);
                 const u64 d = b + cr[e];
                 ls[e] = d;
                 hs[e] = (mid >> 35) + (c2[e] >> 6) + (a < c0[e] ? 1 : 0) + (b < a ? 1 : 0) + (d < b ? 1 : 0);
+#else                                // one 128-bit sum: the carries ride the v_addc chain
+                const unsigned __int128 sum = (unsigned __int128)c0[e] + ((unsigned __int128)mid << 29) + ((unsigned __int128)c2[e] << 58) + cr[e];
+                ls[e] = (u64)sum;
+                hs[e] = (u64)(sum >> 64);
+#endif
             }
             r0 = csub(mont_redc_lazy(hs[0], ls[0], m.q, m.qinv), m.q);
             r1 = csub(mont_redc_lazy(hs[1], ls[1], m.q, m.qinv), m.q);
