@@ -441,13 +441,16 @@ LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 #define LSA_NTT_STORE_CHUNK 4
 #endif
 struct NttStoreFix {   // per-block constants of the store-side conversions
-    bool fp, final_reduce, tail, with_base, merged, raw;
+    bool fp, final_reduce, tail, with_base, merged, raw, skip_reduce;
     u64 q, qinv, k, k2;
     double qd, qinvd, kd, k2d;   // kd/k2d: the tail factors as plain doubles (FP64-engine limbs)
 };
 LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
     if (f.fp) {
-        double r = fp_reduce(d_from_bits(v), f.qd, f.qinvd);   // |r| <= q/2 (+ rounding slack)
+        // the store's own reduction is skipped where it changes nothing that matters: inverse passes end every sub-pass
+        // reduced already, and the hand-off of a forward transform whose modulus is below 2^46 stays below 2^51 unreduced
+        // (|in| < 4q, + 1.1q per stage over <= 17 stages: 22.7q < 2^50.6)
+        double r = f.skip_reduce ? d_from_bits(v) : fp_reduce(d_from_bits(v), f.qd, f.qinvd);   // |r| <= q/2 (+ rounding slack)
         if (f.raw) return d_to_bits(r);   // first pass of a two-pass transform: the second pass's butterflies start from this
         if (f.tail) {   // the fused tail of an FP64-engine limb stays on the FP64 engine: exact, 6 operations per product
             const double ad = u52_to_double(va), bd = f.with_base ? u52_to_double(vb) : 0.0;
@@ -498,6 +501,7 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     f.fp = bc.fp != 0;
     f.final_reduce = a.final_reduce != 0;
     f.raw = f.fp && a.fp_raw_out;
+    f.skip_reduce = f.fp && (a.inverse || (f.raw && (md.q >> 46) == 0));
     f.tail = FZ && a.fz_epi && a.final_reduce;
     f.q = md.q;
     f.qinv = md.qinv;
@@ -705,6 +709,7 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
                         const double T = fp_modmul(v[e + half], w[e >> (RHO - j)], q, qinv);
 #endif
                         const double U = v[e];
+                        LSA_EMU_CHECK(__builtin_fabs(U) < 2251799813685248.0 && __builtin_fabs(v[e + half]) < 2251799813685248.0);   // 2^51: the engine's exactness bound
                         v[e] = U + T;          // |.| grows by < 1.1q per stage: <= 10.9q < 2^51 over a 9-stage pass
                         v[e + half] = U - T;
                     }
