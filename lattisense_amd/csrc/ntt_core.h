@@ -150,6 +150,28 @@ LSA_HD unsigned ntt_tw_v_fp(int j, unsigned G) {
 }
 LSA_HD long long ntt_tw_pos_int(int s, int j, long long G, int k) { return ntt_tw_u_int(s, j, k) + ntt_tw_v_int(j, (unsigned)G); }
 LSA_HD long long ntt_tw_pos_fp(int s, int j, long long G, int k) { return ntt_tw_u_fp(s, j, k) + ntt_tw_v_fp(j, (unsigned)G); }
+// The tile's own data and the fused tails' operands are read once and written once per pass: they go through the memory
+// pipeline with the NON-TEMPORAL policy (`nt`: served by L2, no L1 allocation), which leaves the CU's L1 to the per-point
+// constants.  FP64-engine transforms +5-8 % (N = 2^14 whole-limb plan +10-15 %), integer +4-7 %, headline +2.4 %, rotate
+// +2.7 %, BFV +3 % (profiles/r02/ab_ntt_nontemporal_tile_data.log).  The same policy on the element-wise kernels' streams
+// changes nothing.  -DLSA_NTT_NO_NT builds the default-policy accesses (A/B).
+#if !defined(LSA_NTT_NO_NT)
+typedef u64 lsa_v2u64 __attribute__((ext_vector_type(2)));
+#endif
+LSA_HD void ntt_load_data_pair(const u64* p, u64& x, u64& y) {   // 16-byte aligned; the tile's own data
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LSA_NTT_NO_NT)
+    const lsa_v2u64 v = __builtin_nontemporal_load(reinterpret_cast<const lsa_v2u64*>(p));
+    x = v.x;
+    y = v.y;
+#elif defined(__HIP_DEVICE_COMPILE__)
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p);
+    x = v.x;
+    y = v.y;
+#else
+    x = p[0];
+    y = p[1];
+#endif
+}
 LSA_HD void ntt_load_pair(const u64* p, u64& x, u64& y) {   // 16-byte aligned
 #if defined(__HIP_DEVICE_COMPILE__)
     const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p);
@@ -351,14 +373,7 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
 #pragma unroll
         for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
             const int x = ntt_tile_index(tm, 2 * (tid + p * NT));
-#if defined(__HIP_DEVICE_COMPILE__)
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g + x);
-            st[2 * p] = v.x;
-            st[2 * p + 1] = v.y;
-#else
-            st[2 * p] = g[x];
-            st[2 * p + 1] = g[x + 1];
-#endif
+            ntt_load_data_pair(g + x, st[2 * p], st[2 * p + 1]);
         }
 #pragma unroll
         for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
@@ -376,8 +391,8 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
 #pragma unroll
             for (int p = 0; p < CH; p++) {
                 const int x = ntt_tile_index(tm, 2 * (tid + (p0 + p) * NT));
-                ntt_load_pair(g + x, st[2 * p], st[2 * p + 1]);
-                ntt_load_pair(gl + x, sl[2 * p], sl[2 * p + 1]);
+                ntt_load_data_pair(g + x, st[2 * p], st[2 * p + 1]);
+                ntt_load_data_pair(gl + x, sl[2 * p], sl[2 * p + 1]);
             }
 #pragma unroll
             for (int p = 0; p < CH; p++) {
@@ -482,7 +497,12 @@ LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
     return v;
 }
 LSA_HD void ntt_store_pair(u64* gp, u64 v0, u64 v1) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LSA_NTT_NO_NT)
+    lsa_v2u64 w;
+    w.x = v0;
+    w.y = v1;
+    __builtin_nontemporal_store(w, reinterpret_cast<lsa_v2u64*>(gp));
+#elif defined(__HIP_DEVICE_COMPILE__)
     ulonglong2 w;
     w.x = v0;
     w.y = v1;
@@ -540,12 +560,10 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
                 v[2 * p + 1] = lds[lds_addr(l + 1)];
                 va[2 * p] = va[2 * p + 1] = vb[2 * p] = vb[2 * p + 1] = 0;
                 if (f.tail) {
-                    va[2 * p] = pa[x];
-                    va[2 * p + 1] = pa[x + 1];
+                    ntt_load_data_pair(pa + x, va[2 * p], va[2 * p + 1]);
                 }
                 if (f.with_base) {
-                    vb[2 * p] = pb[x];
-                    vb[2 * p + 1] = pb[x + 1];
+                    ntt_load_data_pair(pb + x, vb[2 * p], vb[2 * p + 1]);
                 }
             }
 #pragma unroll
