@@ -45,35 +45,112 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=4)
     ap.add_argument("--log-slots", type=int, default=0, help="bootstrap workload: log2 of the packed slots (0 = dense, N/2)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N started plainly: overall deadline in seconds for the ranks this process starts")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch path only: every rank joins a gloo group, rank 0 prints what it sees (no GPU work; CPU test)")
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """Number of GPUs this process may use, found WITHOUT loading a GPU runtime (no torch, no HIP: a launcher that has
+    initialised HIP must not start other programs on this pool).  KFD topology nodes with SIMDs are the GPUs; the
+    *_VISIBLE_DEVICES variables narrow the set.  None = cannot tell from here (no KFD sysfs): the ranks check for themselves."""
+    import glob
+    n = None
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if nodes:
+        n = 0
+        for f in nodes:
+            try:
+                for ln in open(f):
+                    k, _, v = ln.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+            except (OSError, ValueError):
+                pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([x for x in v.split(",") if x.strip() != ""])
+            n = listed if n is None else min(n, listed)
+    return n
+
+
+def profiler_preloaded():
+    """rocprofv3 & co. preload a tool library that initialises the GPU before main(): starting ranks from such a process is
+    the fork+exec this pool forbids.  Counter / trace runs are --gpus 1 (or one profiler per rank under torchrun)."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return ("rocprof" in pre or "roctracer" in pre or "ROCP_TOOL_LIBRARIES" in os.environ
+            or "ROCPROFILER_REGISTER_FORCE_LOAD" in os.environ or "ROCPROF_OUTPUT_PATH" in os.environ)
+
+
 def self_launch(args):
     """`bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set)
-    BEFORE this process touches the GPU, wait for them and return the worst exit code.  Rank 0 prints the JSON line on the
-    shared stdout.  (The reference's multi-GPU usage is one device index per call, README.md:195-202; its harness
-    examples/benchmark_gpu/benchmark_gpu.cpp:27-52 takes the device the same way.)"""
+    from a parent that never loads torch or HIP, poll them, and on the first failure (or the overall deadline) stop the
+    others -- ranks blocked in the RCCL rendezvous / broadcast / barrier would otherwise sit there until the driver's
+    timeout.  Returns the first non-zero exit code.  Rank 0 prints the JSON line on the shared stdout.  (The reference's
+    multi-GPU usage is one device index per call, README.md:195-202; its harness examples/benchmark_gpu/benchmark_gpu.cpp:27-52
+    takes the device the same way.)"""
+    import signal
     import socket
     import subprocess
     n = args.gpus
+    if profiler_preloaded():
+        raise SystemExit("bench.py --gpus %d under a profiler preload: the launcher would start ranks from a GPU-initialised "
+                         "process; profile with --gpus 1, or wrap each rank under torchrun" % n)
     if not args.dry_launch:
-        import torch
-        have = torch.cuda.device_count()   # counts devices without initialising them
-        if have < n:
+        have = visible_gpu_count()
+        if have is not None and have < n:
             raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # the proof the CPU test reads: nothing GPU-related was imported into the process that starts the ranks
+    gpu_mods = sorted(m for m in sys.modules if m == "torch" or m.startswith("torch.") or m.startswith("lattisense_amd"))
+    print("launcher: " + json.dumps({"pid": os.getpid(), "ranks": n, "port": port, "gpu_modules_loaded": gpu_mods}),
+          file=sys.stderr, flush=True)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
+        # own process group per rank: stopping a rank also stops whatever it started
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+
+    def stop_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    deadline = time.monotonic() + args.launch_timeout
+    rc, why = 0, None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = abs(bad[0][1]) or 1
+                why = "rank %d exited with code %d" % bad[0]
+                break
+            if all(c == 0 for c in codes):
+                return 0
+            if time.monotonic() > deadline:
+                rc, why = 124, "no result after %.0f s (--launch-timeout)" % args.launch_timeout
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc, why = 130, "interrupted"
+    print("launcher: %s; stopping the other ranks" % why, file=sys.stderr, flush=True)
+    stop_all(signal.SIGTERM)
+    t_kill = time.monotonic() + 5.0
+    while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+        time.sleep(0.05)
+    stop_all(signal.SIGKILL)
     for p in procs:
-        rc = max(rc, abs(p.wait()))
+        p.wait()
     return rc
 
 
@@ -83,6 +160,8 @@ def dry_launch(args):
     import torch.distributed as dist
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("LSA_DRY_FAIL_RANK") == str(rank):   # test hook: this rank dies before the rendezvous
+        sys.exit(3)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     seen = [None] * world
     dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ["LOCAL_RANK"]), "pid": os.getpid()})
