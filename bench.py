@@ -578,6 +578,7 @@ def main():
             "config": {"workload": cfg["label"], "batch_per_gpu": batch, "ring_degree": n, "q_limbs": L,
                        "special_primes": len(cfg["p"]), "sharding": "ciphertext batch by rank; key broadcast once"},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+            "build_flags": L_.lsa_build_flags().decode(),   # "" = the product library (csrc/build_flags.h)
         }
         print(json.dumps(line), flush=True)
     if world > 1:

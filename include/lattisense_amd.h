@@ -34,6 +34,8 @@ enum { LSA_ALGO_BFV = 0, LSA_ALGO_CKKS = 1 }; /* same values as Algo in mega_ag_
 
 const char* lsa_last_error(void);
 const char* lsa_version(void);
+/* every compile-time switch (LSA_* macro) the library was built with; "" for the product build (csrc/build_flags.h) */
+const char* lsa_build_flags(void);
 
 /* ---- context: replaces init_gpu_context (gpu_wrapper.cu:53-138).  q = Q chain (max_level+1 primes),
  * p = special primes, t = BFV plaintext modulus (0 for CKKS).  Tables are built once and cached. */

@@ -39,6 +39,7 @@ SIGNATURES = {
     # name: (restype, argtypes)
     "lsa_last_error": (ctypes.c_char_p, []),
     "lsa_version": (ctypes.c_char_p, []),
+    "lsa_build_flags": (ctypes.c_char_p, []),
     "lsa_context_create": (c_int, [c_int, c_int, c_u64p, c_int, c_u64p, c_int, ctypes.c_uint64, c_int,
                                    ctypes.POINTER(c_vp)]),
     "lsa_context_destroy": (c_int, [c_vp]),
@@ -113,8 +114,19 @@ def lib():
             fn = getattr(L, name)  # AttributeError here == the .so does not export what the header declares
             fn.restype = res
             fn.argtypes = args
+        flags = L.lsa_build_flags().decode()
+        if flags and not os.environ.get("LSA_NATIVE_LIB"):
+            # a library at the product's path must be the product: A/B and diagnostic builds (some compute wrong results on
+            # purpose) live under variants/ and are only ever selected explicitly through LSA_NATIVE_LIB
+            raise RuntimeError("%s was built with switches [%s]: not the product build; rebuild with "
+                               "`python -m lattisense_amd.build --force`" % (LIB_PATH, flags))
         _lib = L
     return _lib
+
+
+def build_flags():
+    """The LSA_* switches of the loaded library ("" = product build)."""
+    return lib().lsa_build_flags().decode()
 
 
 def check(rc):

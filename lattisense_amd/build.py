@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblattisense_amd.so")
 HIP_SOURCES = ["kernels.hip", "context.hip", "ops.hip", "bootstrap.hip", "c_api.hip", "task_runtime.hip"]
 CXX_SOURCES = ["tables.cpp", "task_graph.cpp"]
-HEADERS = ["modarith.h", "ntt_core.h", "ntt_plan.h", "tables.h", "lsa_internal.h", "task_graph.h", "mini_json.h", "buf_pool.h",
+HEADERS = ["build_flags.h", "modarith.h", "ntt_core.h", "ntt_plan.h", "tables.h", "lsa_internal.h", "task_graph.h", "mini_json.h", "buf_pool.h",
            "../../include/lattisense_amd.h", "../../include/lattisense_task.h"]
 
 
@@ -43,8 +43,7 @@ def build_native(force=False, verbose=False):
         if force or _stale(obj, [sp] + hdrs):
             if src.endswith(".hip"):
                 cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                       "-fno-fast-math", "-Wall", "-Wno-unused-result"] + os.environ.get("LSA_EXTRA_FLAGS", "").split() + \
-                      ["-c", sp, "-o", obj]
+                       "-fno-fast-math", "-Wall", "-Wno-unused-result", "-c", sp, "-o", obj]   # no -D switches, whatever the environment says
             else:
                 cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-I/opt/rocm/include",
                        "-D__HIP_PLATFORM_AMD__", "-c", sp, "-o", obj]
@@ -54,7 +53,7 @@ def build_native(force=False, verbose=False):
     if force or _stale(LIB, objs):
         tl = torch_lib_dir()
         libdirs = ([tl] if tl else []) + ["/opt/rocm/lib"]
-        cmd = ["g++", "-shared", "-o", LIB] + objs
+        cmd = ["g++", "-shared", "-Wl,-soname,liblattisense_amd.so", "-o", LIB] + objs
         for d in libdirs:
             cmd += ["-L" + d, "-Wl,-rpath," + d]
         cmd += ["-lamdhip64", "-lpthread"]
@@ -67,9 +66,15 @@ def build_native(force=False, verbose=False):
 def build_variant(name, flags, verbose=False):
     """A/B builds for measurement: the same library with extra compile flags, as lattisense_amd/variants/lib<name>.so
     (selected at run time with LSA_NATIVE_LIB=<path>; diagnostics only -- tests and bench use the default build).
-    Objects are cached per variant; only sources whose text mentions one of the -D names are recompiled with the flags."""
+    Objects are cached per variant; only sources whose text mentions one of the -D names are recompiled with the flags,
+    plus the three that report the flag string (csrc/build_flags.h).  Wrong-result diagnostics (*_DIAG_NO_*, *_COPY_ONLY,
+    *_COMPUTE_ONLY) get -DLSA_DIAG_BUILD and the library its own SONAME: it cannot stand in for the product."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     build_native()
+    diag = any(t in flags for t in ("_DIAG_NO_", "_DIAG_COPY_ONLY", "_DIAG_COMPUTE_ONLY"))
+    if diag and "-DLSA_DIAG_BUILD" not in flags:
+        flags = flags + " -DLSA_DIAG_BUILD"
+    flags = flags + " -DLSA_VARIANT_NAME=" + name
     vdir = os.path.join(HERE, "variants")
     objdir = os.path.join(CSRC, "build", "variant_" + name)
     os.makedirs(vdir, exist_ok=True)
@@ -82,7 +87,8 @@ def build_variant(name, flags, verbose=False):
         sp = os.path.join(CSRC, src)
         base_obj = os.path.join(CSRC, "build", src.replace(".", "_") + ".o")
         text = open(sp).read()
-        affected = src.endswith(".hip") and (not macros or any(m in text or (m in hdr_text and src == "kernels.hip") for m in macros))
+        affected = src.endswith(".hip") and (src in ("kernels.hip", "context.hip", "c_api.hip") or
+                                             any(m in text for m in macros))
         if not affected:
             objs.append(base_obj)
             continue
@@ -98,7 +104,7 @@ def build_variant(name, flags, verbose=False):
             open(stamp, "w").write(flags)
     out = os.path.join(vdir, "lib%s.so" % name)
     tl = torch_lib_dir()
-    cmd = ["g++", "-shared", "-o", out] + objs
+    cmd = ["g++", "-shared", "-Wl,-soname,liblattisense_amd_%s_%s.so" % ("diag" if diag else "variant", name), "-o", out] + objs
     for d in ([tl] if tl else []) + ["/opt/rocm/lib"]:
         cmd += ["-L" + d, "-Wl,-rpath," + d]
     cmd += ["-lamdhip64", "-lpthread"]

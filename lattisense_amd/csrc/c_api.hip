@@ -1,8 +1,11 @@
 // c_api.hip — extern "C" operator layer (include/lattisense_amd.h).  Every entry point converts C++ exceptions into
 // error codes: nothing throws across the C boundary (the reference does, SURVEY §8b "Errors").
+#include "build_flags.h"
 #include "lsa_internal.h"
 
 namespace lsa {
+const char* kernels_build_flags();   // kernels.hip / context.hip: what THOSE translation units were compiled with
+const char* context_build_flags();
 void ckks_mult(Context&, int, const u64*, const u64*, u64*, int, long long, long long, long long, hipStream_t);
 void ckks_relin(Context&, int, const u64*, const Key&, u64*, int, long long, long long, hipStream_t);
 void ckks_rescale(Context&, int, int, const u64*, u64*, int, long long, long long, hipStream_t);
@@ -63,6 +66,17 @@ extern "C" {
 
 const char* lsa_last_error(void) { return last_error().c_str(); }
 const char* lsa_version(void) { return "lattisense_amd 0.1 (gfx950)"; }
+// every LSA_* switch the library was compiled with (build_flags.h); "" for the product build.  The three translation units
+// that carry switches must agree; if they do not, each view is reported.
+const char* lsa_build_flags(void) {
+    static const std::string text = [] {
+        auto strip = [](const char* t) { return std::string(t[0] == ' ' ? t + 1 : t); };
+        const std::string a = strip(LSA_BUILD_FLAGS_TEXT), k = strip(kernels_build_flags()), c = strip(context_build_flags());
+        if (a == k && a == c) return a;
+        return "MIXED c_api=[" + a + "] kernels=[" + k + "] context=[" + c + "]";
+    }();
+    return text.c_str();
+}
 
 int lsa_context_create(int algo, int n, const uint64_t* q, int nq, const uint64_t* p, int np, uint64_t t, int device,
                        lsa_context* out) {

@@ -1,8 +1,11 @@
 // context.hip — parameter-set context: device tables, cached conversion plans, workspace.
+#include "build_flags.h"
 #include "lsa_internal.h"
 #include <cstdlib>
 
 namespace lsa {
+
+const char* context_build_flags() { return LSA_BUILD_FLAGS_TEXT; }
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& m) { g_last_error = m; }

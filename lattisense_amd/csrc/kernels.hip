@@ -1,10 +1,14 @@
 // kernels.hip — hand-written gfx950 kernels for the RNS hot path and their launchers.
 // HBM-bound integer work: 16 B/lane coalesced accesses, LDS-staged butterflies, no MFMA (no dense FP contraction here).
 #include <atomic>
+#include <cstdlib>
 
+#include "build_flags.h"
 #include "lsa_internal.h"
 
 namespace lsa {
+
+const char* kernels_build_flags() { return LSA_BUILD_FLAGS_TEXT; }
 
 static constexpr int TPB = 256;
 
@@ -12,9 +16,6 @@ static constexpr int TPB = 256;
 #ifndef LSA_NTT_WAVES
 #define LSA_NTT_WAVES 4   // min waves/SIMD the register allocator must allow (= co-resident 256-thread workgroups per CU):
                           // 4 = at most 128 VGPRs; the plain and epilogue-only variants fit without spilling
-#endif
-#ifndef LSA_NTT_TILES_PER_WG
-#define LSA_NTT_TILES_PER_WG 1   // >1: a workgroup walks this many consecutive tiles, prefetching tile k+1 during tile k
 #endif
 
 #if defined(LSA_NTT_DIAG_STAMPS)   // diagnostic build: shader-clock stamp k of this workgroup (first 8192 workgroups)
@@ -64,7 +65,6 @@ template <int FZ, int NT, bool TWL = false>
 __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : (FZ & 1) ? LSA_NTT_WAVES_FUSED : LSA_NTT_WAVES) void k_ntt_pass(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
-#if LSA_NTT_TILES_PER_WG == 1
     NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
     if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
     ulonglong2 twp = {0, 0};
@@ -112,33 +112,6 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : (FZ & 1) ? LSA_NT
     ntt_butterfly_phases<NT, TWL>(a, bc, tid, lds);
     ntt_phase_store<(FZ & 2) != 0, NT>(a, bc, tid, lds);
     LSA_STAMP(7);
-#else
-    // software-pipelined walk over consecutive tiles (same limb and tile index, different batch items: same twiddles)
-    const long long first = (long long)blockIdx.x * LSA_NTT_TILES_PER_WG;
-    u64 stage[2 * LSA_NTT_STAGE_PAIRS];
-    NttBlockCtx nxt = ntt_decode_block(a, first < a.total_tiles ? first : 0);
-    bool have_nxt = first < a.total_tiles && nxt.mod != LSA_ROW_SKIP;
-    if (have_nxt) ntt_phase_fetch<NT>(a, nxt, tid, stage);
-    for (int k = 0; k < LSA_NTT_TILES_PER_WG; k++) {
-        const long long bid = first + k;
-        if (bid >= a.total_tiles) break;
-        const NttBlockCtx bc = nxt;
-        const bool have = have_nxt;
-        have_nxt = false;
-        if (k + 1 < LSA_NTT_TILES_PER_WG && bid + 1 < a.total_tiles) {
-            nxt = ntt_decode_block(a, bid + 1);
-            have_nxt = nxt.mod != LSA_ROW_SKIP;
-        }
-        if (have) ntt_phase_commit<NT>(a, bc, tid, lds, stage);
-        __syncthreads();
-        if (have_nxt) ntt_phase_fetch<NT>(a, nxt, tid, stage);   // in flight during the butterflies below
-        if (have) {
-            ntt_butterfly_phases<NT>(a, bc, tid, lds);
-            ntt_phase_store<(FZ & 2) != 0, NT>(a, bc, tid, lds);
-        }
-        __syncthreads();   // LDS is reused by the next tile
-    }
-#endif
 }
 
 template <int FZ, int NT>
@@ -281,7 +254,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
             a.dst = dst + (long long)b0 * dst_stride;
             a.dst_stride = dst_stride;
             a.total_tiles = (long long)nb * launch_rows * (1 << (a.logn - a.tau));
-            const long long nblocks = (a.total_tiles + LSA_NTT_TILES_PER_WG - 1) / LSA_NTT_TILES_PER_WG;
+            const long long nblocks = a.total_tiles;
             LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
             const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
             // one launch = one pass = 1/npass of the limb transforms it touches (algorithmic 16*N bytes per transform)

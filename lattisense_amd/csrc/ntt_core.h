@@ -410,46 +410,6 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
     }
 }
 
-// The load phase split in two for software pipelining (async-STAGE split): `fetch` only ISSUES the tile's global loads
-// into registers (they stay in flight while the previous tile's butterflies run), `commit` writes them to LDS later.
-template <int NT>
-LSA_HD void ntt_phase_fetch(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* stage /*[2*PAIRS]*/) {
-    const u64* g = a.src + bc.base_src;
-    const int half = 1 << (a.tau - 1);
-#pragma unroll
-    for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
-        const int i = tid + p * NT;
-        if (i < half) {
-            const int x = ntt_global_index(a, bc.tile, 2 * i);
-#if defined(__HIP_DEVICE_COMPILE__)
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(g + x);
-            stage[2 * p] = v.x;
-            stage[2 * p + 1] = v.y;
-#else
-            stage[2 * p] = g[x];
-            stage[2 * p + 1] = g[x + 1];
-#endif
-        }
-    }
-}
-template <int NT>
-LSA_HD void ntt_phase_commit(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, const u64* stage) {
-    const int half = 1 << (a.tau - 1);
-#pragma unroll
-    for (int p = 0; p < LSA_NTT_STAGE_PAIRS; p++) {
-        const int i = tid + p * NT;
-        if (i < half) {
-            u64 v0 = stage[2 * p], v1 = stage[2 * p + 1];
-            if (bc.fp) {
-                v0 = d_to_bits(u52_to_double(v0));
-                v1 = d_to_bits(u52_to_double(v1));
-            }
-            lds[lds_addr(2 * i)] = v0;
-            lds[lds_addr(2 * i + 1)] = v1;
-        }
-    }
-}
-
 // final phase: LDS -> global.  Full tiles go in chunks of LSA_NTT_STORE_CHUNK pairs per thread: a chunk's LDS reads and
 // (fused tail) operand loads are all issued before the first is consumed, for the same reason as in the load phase.
 #ifndef LSA_NTT_STORE_CHUNK

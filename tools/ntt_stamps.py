@@ -1,4 +1,4 @@
-"""Per-phase shader-clock breakdown of one NTT pass (needs a build with LSA_EXTRA_FLAGS=-DLSA_NTT_DIAG_STAMPS).
+"""Per-phase shader-clock breakdown of one NTT pass (needs the variant build `python -m lattisense_amd.build --variant stamps -DLSA_NTT_DIAG_STAMPS`, selected with LSA_NATIVE_LIB=lattisense_amd/variants/libstamps.so).
 Stamps per workgroup: 0 start, 1 loads issued, 2 tile in LDS (barrier), 3/4 sub-pass 1 done / barrier, 5/6 sub-pass 2, 7 stores issued."""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
