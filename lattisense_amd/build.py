@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblattisense_amd.so")
 HIP_SOURCES = ["kernels.hip", "context.hip", "ops.hip", "bootstrap.hip", "c_api.hip", "task_runtime.hip"]
 CXX_SOURCES = ["tables.cpp", "task_graph.cpp"]
-HEADERS = ["build_flags.h", "modarith.h", "ntt_core.h", "ntt_plan.h", "tables.h", "lsa_internal.h", "task_graph.h", "mini_json.h", "buf_pool.h",
+HEADERS = ["build_flags.h", "modarith.h", "ntt_core.h", "ntt_r16.h", "ntt_plan.h", "tables.h", "lsa_internal.h", "task_graph.h", "mini_json.h", "buf_pool.h",
            "../../include/lattisense_amd.h", "../../include/lattisense_task.h"]
 
 

@@ -4,6 +4,8 @@
 #include <cstddef>
 #include <vector>
 #include "ntt_plan.h"
+#include "ntt_r16.h"
+#include <array>
 #include "tables.h"
 
 template <int NT>
@@ -27,9 +29,21 @@ static void emu_block(const NttPassArgs& a, const NttBlockCtx& bc, u64* lds) {
     for (int t = 0; t < NT; t++) ntt_phase_store<true, NT>(a, bc, t, lds);
 }
 
+// the radix-16-squared pass (ntt_r16.h): each phase for every thread in turn, a thread's registers kept between its phases
+template <int PASS>
+static void emu_block_r16(const NttPassArgs& a, const NttBlockCtx& bc, u64* lds) {
+    std::vector<std::array<u64, 16>> regs(LSA_R16_THREADS);
+    for (int phase = 0; phase < 3; phase++)
+        for (int t = 0; t < LSA_R16_THREADS; t++) {
+            u64(&v)[16] = *reinterpret_cast<u64(*)[16]>(regs[t].data());
+            r16_phase<PASS, 3>(a, bc, t, lds, phase, v);
+        }
+}
+
 extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int batch, long long batch_stride, int rows,
                            const unsigned char* mod_of, int period, int inverse, int tau_max, int allow_fp64) {
-    const int row_inner = allow_fp64 >> 1;   // bit 1: the (tile, row, batch) workgroup order
+    const int row_inner = (allow_fp64 >> 1) & 1;   // bit 1: the (tile, row, batch) workgroup order
+    const bool r16 = (allow_fp64 >> 2) & 1;        // bit 2: 8-stage passes through the radix-16-squared kernel
     allow_fp64 &= 1;
     lsa::HostTables T;
     T.build(n, std::vector<u64>(moduli, moduli + nmod));
@@ -76,7 +90,10 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
         for (long long bid = 0; bid < nblocks; bid++) {
             NttBlockCtx bc = ntt_decode_block(a, bid);
             if (bc.mod == LSA_ROW_SKIP) continue;
-            if (a.tau <= 12) emu_block<LSA_NTT_THREADS>(a, bc, lds.data());
+            if (r16 && ntt_r16_shape_ok(a, plan.npass)) {
+                if (a.lambda) emu_block_r16<0>(a, bc, lds.data());
+                else emu_block_r16<1>(a, bc, lds.data());
+            } else if (a.tau <= 12) emu_block<LSA_NTT_THREADS>(a, bc, lds.data());
             else if (a.tau == 13) emu_block<512>(a, bc, lds.data());
             else emu_block<1024>(a, bc, lds.data());
         }

@@ -5,6 +5,7 @@
 
 #include "build_flags.h"
 #include "lsa_internal.h"
+#include "ntt_r16.h"
 
 namespace lsa {
 
@@ -112,6 +113,67 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : NT > 256 ? 2 : (FZ & 1) ? LSA_NT
     ntt_butterfly_phases<NT, TWL>(a, bc, tid, lds);
     ntt_phase_store<(FZ & 2) != 0, NT>(a, bc, tid, lds);
     LSA_STAMP(7);
+}
+
+// ---- the 8-stage passes of two-pass plans: 16 x 16 register butterflies, one LDS exchange (ntt_r16.h)
+// PASS 0 (first pass): the exchange crosses wavefronts -> one workgroup barrier.  PASS 1 (second pass): a 256-point transform
+// lives in 16 lanes of one wavefront, LDS instructions of a wavefront execute in order: the exchanges need no barrier, only
+// that the compiler keeps the LDS accesses in program order (wavefront-scope fences).
+template <int PASS>
+__device__ __forceinline__ void r16_sync() {
+#if defined(LSA_R16_BARRIERS)   // A/B: workgroup barriers in the second pass too
+    __syncthreads();
+#else
+    if (PASS == 0) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#endif
+}
+#ifndef LSA_R16_WAVES
+#define LSA_R16_WAVES 4
+#endif
+template <int PASS, int FZ>
+__global__ __launch_bounds__(LSA_R16_THREADS, (FZ & 1) ? LSA_NTT_WAVES_FUSED : LSA_R16_WAVES) void k_ntt_r16(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
+    if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
+    u64 v[16];
+    r16_phase<PASS, FZ>(a, bc, tid, lds, 0, v);
+    if (!(PASS == 0 && a.inverse)) r16_sync<PASS>();   // (first pass, inverse: phase 0 only filled registers)
+    r16_phase<PASS, FZ>(a, bc, tid, lds, 1, v);
+    if (PASS == 0 && !a.inverse) return;                // (first pass, forward: phase 1 stored the results)
+    r16_sync<PASS>();
+    r16_phase<PASS, FZ>(a, bc, tid, lds, 2, v);
+}
+static bool ntt_launch_r16(const NttPassArgs& a, int npass, bool fused, long long nblocks, hipStream_t s) {
+    static const bool enabled = [] {
+        const char* e = getenv("LSA_NTT_R16");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled || !ntt_r16_shape_ok(a, npass)) return false;
+    const bool pro = fused && a.fz_pro && a.s_lo == 0, epi = fused && a.fz_epi && a.final_reduce;
+    const size_t lds_bytes = (size_t)LSA_R16_LDS_WORDS * sizeof(u64);
+    const dim3 grid((unsigned)nblocks), block(LSA_R16_THREADS);
+    static const bool pro_enabled = [] {   // A/B: the fused-prologue first pass on the staged kernel
+        const char* e = getenv("LSA_R16_PRO");
+        return !(e && e[0] == '0');
+    }();
+    if (a.lambda) {
+        if (epi || (pro && !pro_enabled)) return false;   // (a first pass is never the last one of a two-pass plan)
+        if (pro) hipLaunchKernelGGL((k_ntt_r16<0, 1>), grid, block, lds_bytes, s, a);
+        else hipLaunchKernelGGL((k_ntt_r16<0, 0>), grid, block, lds_bytes, s, a);
+    } else {
+        if (pro) return false;
+        if (epi) hipLaunchKernelGGL((k_ntt_r16<1, 2>), grid, block, lds_bytes, s, a);
+        else hipLaunchKernelGGL((k_ntt_r16<1, 0>), grid, block, lds_bytes, s, a);
+    }
+    LSA_HIP(hipGetLastError());
+    return true;
 }
 
 template <int FZ, int NT>
@@ -259,6 +321,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
             const size_t lds_bytes = (size_t)lds_words(a.tau) * sizeof(u64);
             // one launch = one pass = 1/npass of the limb transforms it touches (algorithmic 16*N bytes per transform)
             ProfScope ps(c, PROF_NTT, 16.0 * c.n * active_rows * nb / plan.npass, s);
+            if (ntt_launch_r16(a, plan.npass, fz != nullptr, nblocks, s)) continue;
             if (a.tau <= 12) ntt_launch_pass<LSA_NTT_THREADS>(a, fz != nullptr, nblocks, lds_bytes, s);
             else if (a.tau == 13) ntt_launch_pass<512>(a, fz != nullptr, nblocks, lds_bytes, s);
             else ntt_launch_pass<1024>(a, fz != nullptr, nblocks, lds_bytes, s);

@@ -135,10 +135,36 @@ LSA_HD u32 mulhi32(u32 a, u32 b) {
 #endif
 }
 // w*v mod q in [0, 4q) for ANY 64-bit v; w < q with its quotient ws = floor(w * 2^64 / q), nq = 2^64 - q
+// Device form: the nine multiply-adds as TWO asm blocks.  hipcc puts an `s_nop 0` after every single-instruction asm
+// statement that is followed by another one (it cannot see inside and plays safe; its own back-to-back dependent
+// v_mad_u64_u32 carry none -- the hardware interlocks them): written one per statement the product had 6 of them and two
+// register moves for the final recombination, a fifth of the butterfly's issue slots.
 LSA_HD u64 shoup_mul_approx(u64 v, u64 w, u64 ws, u64 nq) {
     const u32 vl = (u32)v, vh = (u32)(v >> 32), wl = (u32)w, wh = (u32)(w >> 32), sl = (u32)ws, sh = (u32)(ws >> 32);
+    const u32 nl = (u32)nq, nh = (u32)(nq >> 32);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LSA_SHOUP_SINGLE_ASM)
+    const u64 t0 = (u64)mulhi32(vh, sl);
+    const u32 t1 = mulhi32(vl, sh);
+    u64 t, p, r, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4\n\t"
+        "v_mad_u64_u32 %0, %1, %5, 1, %0"
+        : "=&v"(t), "=&s"(cy)
+        : "v"(vh), "v"(sh), "v"(t0), "v"(t1));
+    const u32 tl = (u32)t, th = (u32)(t >> 32);
+    asm("v_mad_u64_u32 %0, %2, %3, %6, 0\n\t"
+        "v_mad_u64_u32 %0, %2, %4, %5, %0\n\t"
+        "v_mad_u64_u32 %0, %2, %7, %10, %0\n\t"
+        "v_mad_u64_u32 %0, %2, %8, %9, %0\n\t"
+        "v_mad_u64_u32 %1, %2, %3, %5, 0\n\t"
+        "v_mad_u64_u32 %1, %2, %7, %9, %1\n\t"
+        "v_lshlrev_b64 %0, 32, %0\n\t"          // r + (p << 32) on whole register pairs: composing the pair from halves in
+        "v_lshl_add_u64 %1, %0, 0, %1"            // C cost up to two register moves per product
+        : "=&v"(p), "=&v"(r), "=&s"(cy)
+        : "v"(vl), "v"(vh), "v"(wl), "v"(wh), "v"(tl), "v"(th), "v"(nl), "v"(nh));
+    return r;
+#else
     const u64 t = mad64(vh, sh, (u64)mulhi32(vh, sl)) + mulhi32(vl, sh);
-    const u32 tl = (u32)t, th = (u32)(t >> 32), nl = (u32)nq, nh = (u32)(nq >> 32);
+    const u32 tl = (u32)t, th = (u32)(t >> 32);
     u64 p = mul64(vl, wh);   // low-word cross terms; the upper word of this chain is never read
     p = mad64(vh, wl, p);
     p = mad64(tl, nh, p);
@@ -146,6 +172,7 @@ LSA_HD u64 shoup_mul_approx(u64 v, u64 w, u64 ws, u64 nq) {
     u64 r = mul64(vl, wl);
     r = mad64(tl, nl, r);
     return r + ((u64)(u32)p << 32);
+#endif
 }
 // a in [0, 2m), m < 2^63: a - m if a >= m (nm = 2^64 - m)
 LSA_HD u64 csub_sign(u64 a, u64 nm) {

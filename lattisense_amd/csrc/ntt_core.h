@@ -182,6 +182,14 @@ LSA_HD void ntt_load_pair(const u64* p, u64& x, u64& y) {   // 16-byte aligned
     y = p[1];
 #endif
 }
+// Twiddles whose position is the same for every lane of the wavefront (the first radix group of a first pass: G = 0) are read
+// through the CONSTANT address space: wave-uniform loads of plain global memory stay on the scalar unit only until the
+// kernel's first store, reads of constant memory always (the tables are never written while a kernel runs).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LSA_CONST_PTR(T, p) ((const __attribute__((address_space(4))) T*)(p))
+#else
+#define LSA_CONST_PTR(T, p) (p)
+#endif
 // the 2^j FP64-engine twiddles of stage s for butterfly group G (tws = the stage's first entry)
 LSA_HD void ntt_load_tw_fp(const double* tws, int s, int j, unsigned G, double* w) {
     const unsigned gv = ntt_tw_v_fp(j, G);
@@ -270,6 +278,13 @@ LSA_HD int ntt_hi_index(const NttPassArgs& a, int tile, int l) {
     return tile >> (lo_bits - a.lambda);
 }
 
+// forward transforms of integer-engine limbs below 2^57 run without per-butterfly conditional subtractions (ntt_group_int)
+#if !defined(LSA_NTT_EXACT_BFLY) && !defined(LSA_NTT_NO_LAZY)
+LSA_HD bool ntt_int_lazy(u64 q) { return (q >> 57) == 0; }
+#else
+LSA_HD bool ntt_int_lazy(u64) { return false; }
+#endif
+
 // ---- FP64 engine primitives (all results exact, see header)
 LSA_HD double d_from_bits(u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -340,11 +355,11 @@ LSA_HD u64 ntt_load_fix(const NttLoadFix& f, u64 v, u64 t) {
     return v;
 }
 // FZ = false compiles the fused prologue out (plain launches: fewer live constants, smaller code)
-template <bool FZ, int NT>
-LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
-    const u64* g = a.src + bc.base_src;
-    const u64* gl = g;   // last-limb source of the head modes
-    const int half = 1 << (a.tau - 1);
+// the load-side constants of a block; g / gl: where the tile's own elements and the last limb's elements are read from
+template <bool FZ>
+LSA_HD NttLoadFix ntt_make_load_fix(const NttPassArgs& a, const NttBlockCtx& bc, const u64*& g, const u64*& gl) {
+    g = a.src + bc.base_src;
+    gl = g;   // last-limb source of the head modes
     NttLoadFix f;
     f.head = FZ && a.fz_pro && a.s_lo == 0;   // fused rescale head: the tile is derived from the (coefficient-domain) last limb
     f.add = f.head && a.fz_pro == 2;
@@ -365,6 +380,14 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
         f.hd = (double)f.h;
         f.qld = (double)f.ql;
     }
+    return f;
+}
+template <bool FZ, int NT>
+LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
+    const u64* g;
+    const u64* gl;
+    const int half = 1 << (a.tau - 1);
+    const NttLoadFix f = ntt_make_load_fix<FZ>(a, bc, g, gl);
     const NttTileMap tm = ntt_tile_map(a, bc.tile);
     if (half == LSA_NTT_STAGE_PAIRS * NT && !f.add) {
         NttLoadFix f1 = f;
@@ -416,8 +439,8 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
 #define LSA_NTT_STORE_CHUNK 4
 #endif
 struct NttStoreFix {   // per-block constants of the store-side conversions
-    bool fp, final_reduce, tail, with_base, merged, raw, skip_reduce;
-    u64 q, qinv, k, k2;
+    bool fp, final_reduce, tail, with_base, merged, raw, skip_reduce, lazy;
+    u64 q, qinv, k, k2, one_s;   // one_s = floor(2^64 / q): the Shoup quotient of w = 1 (entry 0 of the limb's twiddle table)
     double qd, qinvd, kd, k2d;   // kd/k2d: the tail factors as plain doubles (FP64-engine limbs)
 };
 LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
@@ -438,7 +461,8 @@ LSA_HD u64 ntt_store_fix(const NttStoreFix& f, u64 v, u64 va, u64 vb) {
     }
     if (f.final_reduce) {
 #if !defined(LSA_NTT_EXACT_BFLY)
-        v = csub_sign(v, 0 - 4 * f.q);   // forward transforms end below 8q
+        if (f.lazy) v = shoup_mul_approx(v, 1, f.one_s, 0 - f.q);   // lazy forward transform: anything below 2^64 -> [0, 4q)
+        else v = csub_sign(v, 0 - 4 * f.q);   // forward transforms end below 8q
         v = csub_sign(csub_sign(v, 0 - 2 * f.q), 0 - f.q);
 #else
         v = csub(csub(v, 2 * f.q), f.q);
@@ -472,11 +496,11 @@ LSA_HD void ntt_store_pair(u64* gp, u64 v0, u64 v1) {
     gp[1] = v1;
 #endif
 }
-template <bool FZ, int NT>
-LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64* lds) {
-    u64* g = a.dst + bc.base_dst;
+// the store-side constants of a block; g: where results go, pa / pb: the fused tail's operands (placeholders without one)
+template <bool FZ>
+LSA_HD NttStoreFix ntt_make_store_fix(const NttPassArgs& a, const NttBlockCtx& bc, u64*& g, const u64*& pa, const u64*& pb) {
+    g = a.dst + bc.base_dst;
     const ModDev md = a.mods[bc.mod];
-    const int half = 1 << (a.tau - 1);
     NttStoreFix f;
     f.fp = bc.fp != 0;
     f.final_reduce = a.final_reduce != 0;
@@ -490,10 +514,12 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     f.k = f.k2 = 0;
     f.kd = f.k2d = 0.0;
     f.merged = false;
+    f.lazy = !f.fp && !a.inverse && ntt_int_lazy(md.q);
+    f.one_s = f.lazy ? (a.tw + (((long long)bc.mod << a.logn) << 1))[1] : 0;
     const int poly = f.tail ? bc.row / a.fz_limbs : 0, limb = f.tail ? bc.row % a.fz_limbs : 0;
     f.with_base = f.tail && a.fz_base && poly < a.fz_base_polys;
-    const u64* pa = g;   // placeholders when there is no fused tail (never dereferenced)
-    const u64* pb = g;
+    pa = g;   // placeholders when there is no fused tail (never dereferenced)
+    pb = g;
     if (f.tail) {
         pa = a.fz_a + (long long)bc.b * a.fz_a_stride + (((long long)poly * a.fz_a_rpp + limb) << a.logn);
         f.k = a.fz_k[limb];
@@ -506,6 +532,15 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         g = a.fz_out + (long long)bc.b * a.fz_out_stride + (((long long)poly * a.fz_out_rpp + limb) << a.logn);
         if (f.with_base) pb = a.fz_base + (long long)bc.b * a.fz_base_stride + (((long long)poly * a.fz_base_rpp + limb) << a.logn);
     }
+    return f;
+}
+template <bool FZ, int NT>
+LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64* lds) {
+    u64* g;
+    const u64* pa;
+    const u64* pb;
+    const int half = 1 << (a.tau - 1);
+    const NttStoreFix f = ntt_make_store_fix<FZ>(a, bc, g, pa, pb);
     const NttTileMap tm = ntt_tile_map(a, bc.tile);
     if (half == LSA_NTT_STAGE_PAIRS * NT) {
         for (int p0 = 0; p0 < LSA_NTT_STAGE_PAIRS; p0 += LSA_NTT_STORE_CHUNK) {
@@ -541,6 +576,132 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
     }
 }
 
+// The 2^RHO-point butterfly group of a sub-pass -- integer (Shoup) engine.  v[e] are the group's points in local order, s_base
+// the global index of the group's first stage (j = 0), G the group's index at that stage (twiddle table layout above).
+// Forward: stages j = 0..RHO-1 (Cooley-Tukey); inverse: j = RHO-1..0 (Gentleman-Sande); scale_here: the inverse transform's
+// last stage is in this group and folds N^-1 (sc = {N^-1, quotient, psi^-1 N^-1, quotient}).
+template <int RHO, bool TWU, bool lazy>
+LSA_HD void ntt_group_int_impl(u64 (&v)[1 << RHO], bool inverse, const u64* tw /* limb's {w, ws} pairs */, int s_base, unsigned G, u64 q_,
+                               bool scale_here, u64 sc0, u64 sc0s, u64 sc1, u64 sc1s) {
+    constexpr int E = 1 << RHO;
+    const u64 q = q_;
+#if defined(LSA_NTT_EXACT_BFLY)
+    const u64 q2 = 2 * q;
+#else
+    const u64 q4 = 4 * q, nq = 0 - q, nq4 = 0 - q4;
+#endif
+    if (!inverse) {
+#pragma unroll
+        for (int j = 0; j < RHO; j++) {
+            const int half = E >> (j + 1);
+            const int s = s_base + j;
+            const u64* tws = tw + 2 * (1LL << s);
+            u64 w[E / 2], ws[E / 2];   // this stage's 2^j twiddle pairs, one 16-byte load each
+#pragma unroll
+            for (int k = 0; k < (1 << j); k++) {
+                if (TWU) {   // wave-uniform position: scalar loads
+                    w[k] = LSA_CONST_PTR(u64, tws)[2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, G)];
+                    ws[k] = LSA_CONST_PTR(u64, tws)[2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, G) + 1];
+                } else {
+                    ntt_load_pair(tws + 2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, G), w[k], ws[k]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if ((e & half) == 0) {
+                    const int k = e >> (RHO - j);
+#if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)   // diagnostic build: constant twiddle (wrong results, same arithmetic)
+                    const u64 wk = (u64)(G + 2 * k + 3), wsk = (u64)(G + 2 * k + 5) << 40;
+#else
+                    const u64 wk = w[k], wsk = ws[k];
+#endif
+#if defined(LSA_NTT_EXACT_BFLY)   // Harvey's form: values in [0, 4q), exact quotient
+                    u64 U = csub(v[e], q2);
+                    u64 T = shoup_mul_lazy(v[e + half], wk, wsk, q);
+                    v[e] = U + T;
+                    v[e + half] = sub64(U + q2, T);
+#else                             // values in [0, 8q), product in [0, 4q) (modarith.h, shoup_mul_approx)
+                    u64 T = shoup_mul_approx(v[e + half], wk, wsk, nq);
+                    u64 U;
+                    if (lazy) {
+                        // q < 2^57: no conditional subtraction at all.  The product takes ANY 64-bit operand, both outputs are
+                        // below U + 4q: from inputs below 8q a transform of s stages ends below (8 + 4s) q <= 76 q < 2^64 for
+                        // s <= 17; ONE reduction (the same product with w = 1) in the final store.
+                        U = v[e];
+                        LSA_EMU_CHECK(U < 0 - 2 * q4 && T < q4);
+                    } else {
+                        U = csub_sign(v[e], nq4);
+                        LSA_EMU_CHECK(v[e] < 2 * q4 && U < q4 && T < q4);   // the range invariants, checked by the CPU replay
+                    }
+                    v[e] = U + T;
+                    v[e + half] = sub64(U + q4, T);
+#endif
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = RHO - 1; j >= 0; j--) {
+            const int half = E >> (j + 1);
+            const int s = s_base + j;
+            if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
+#pragma unroll
+                for (int e = 0; e < half; e++) {
+                    u64 U = v[e], V = v[e + half];   // both in [0,2q) (exact form) / [0,4q); the exact product lands in [0,2q)
+                    v[e] = shoup_mul_lazy(U + V, sc0, sc0s, q);
+#if defined(LSA_NTT_EXACT_BFLY)
+                    v[e + half] = shoup_mul_lazy(sub64(U + q2, V), sc1, sc1s, q);
+#else
+                    v[e + half] = shoup_mul_lazy(sub64(U + q4, V), sc1, sc1s, q);
+#endif
+                }
+                continue;
+            }
+            const u64* tws = tw + 2 * (1LL << s);
+            u64 w[E / 2], ws[E / 2];
+#pragma unroll
+            for (int k = 0; k < (1 << j); k++) {
+                if (TWU) {   // wave-uniform position: scalar loads
+                    w[k] = LSA_CONST_PTR(u64, tws)[2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, G)];
+                    ws[k] = LSA_CONST_PTR(u64, tws)[2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, G) + 1];
+                } else {
+                    ntt_load_pair(tws + 2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, G), w[k], ws[k]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if ((e & half) == 0) {
+                    const int k = e >> (RHO - j);
+                    u64 U = v[e], V = v[e + half];
+#if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)
+                    const u64 wk = (u64)(G + 2 * k + 3), wsk = (u64)(G + 2 * k + 5) << 40;
+#else
+                    const u64 wk = w[k], wsk = ws[k];
+#endif
+#if defined(LSA_NTT_EXACT_BFLY)   // both in [0,2q)
+                    v[e] = csub(U + V, q2);
+                    v[e + half] = shoup_mul_lazy(sub64(U + q2, V), wk, wsk, q);
+#else                             // both in [0,4q)
+                    LSA_EMU_CHECK(U < q4 && V < q4);
+                    v[e] = csub_sign(U + V, nq4);
+                    v[e + half] = shoup_mul_approx(sub64(U + q4, V), wk, wsk, nq);
+                    LSA_EMU_CHECK(v[e] < q4 && v[e + half] < q4);
+#endif
+                }
+            }
+        }
+    }
+}
+
+// (the lazy form is its own instantiation behind a block-uniform branch: as a run-time flag inside one body the compiler
+// turned it into selects and kept computing the conditional subtractions)
+template <int RHO, bool TWU = false>
+LSA_HD void ntt_group_int(u64 (&v)[1 << RHO], bool inverse, const u64* tw, int s_base, unsigned G, u64 q, bool scale_here, u64 sc0, u64 sc0s,
+                          u64 sc1, u64 sc1s) {
+    if (!inverse && ntt_int_lazy(q)) ntt_group_int_impl<RHO, TWU, true>(v, false, tw, s_base, G, q, false, 0, 0, 0, 0);
+    else ntt_group_int_impl<RHO, TWU, false>(v, inverse, tw, s_base, G, q, scale_here, sc0, sc0s, sc1, sc1s);
+}
+
 // One radix-2^RHO sub-pass over local stages [sig0, sig0+RHO) of the pass — integer (Shoup) engine.
 // LIN: the padded LDS addresses of a group's 2^RHO elements are an arithmetic progression (beta0 == 0 or >= 4), so one
 // add per element replaces the shift/add padding arithmetic.
@@ -549,10 +710,6 @@ template <int RHO, bool LIN, int NT, bool TWL = false>
 LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int sig0) {
     constexpr int E = 1 << RHO;
     const ModDev md = a.mods[bc.mod];
-    const u64 q = md.q, q2 = 2 * md.q;
-#if !defined(LSA_NTT_EXACT_BFLY)
-    const u64 q4 = 4 * md.q, nq = 0 - md.q, nq4 = 0 - q4;
-#endif
     const u64* tw = TWL ? bc.tw_l : a.tw + (((long long)bc.mod << a.logn) << 1);   // {w, ws} pairs
     const int beta0 = a.lambda + a.mu - sig0 - RHO;  // lowest active bit of this sub-pass in l
     const int ngroups = 1 << (a.tau - RHO);
@@ -569,86 +726,81 @@ LSA_HD void ntt_phase_sub(const NttPassArgs& a, const NttBlockCtx& bc, int tid, 
         int r = (lbase >> a.lambda) & ((1 << a.mu) - 1);
         int H = ntt_hi_index(a, bc.tile, lbase);
         int G = (H << sig0) + (r >> (a.mu - sig0));
-        if (!a.inverse) {
+        ntt_group_int<RHO>(v, a.inverse != 0, tw, a.s_lo + sig0, (unsigned)G, md.q, scale_here, sc0, sc0s, sc1, sc1s);
 #pragma unroll
-            for (int j = 0; j < RHO; j++) {
-                const int half = E >> (j + 1);
-                const int s = a.s_lo + sig0 + j;
-                const u64* tws = tw + 2 * (1LL << s);
-                u64 w[E / 2], ws[E / 2];   // this stage's 2^j twiddle pairs, one 16-byte load each
+        for (int e = 0; e < E; e++) lds[LIN ? ad0 + e * adst : lds_addr(lbase + (e << beta0))] = v[e];
+    }
+}
+
+// The same butterfly group on the FP64 engine: integer-valued doubles.  long_pass: a (single-pass) transform of more than 9
+// stages reduces after every forward group; the inverse always does.
+template <int RHO, bool TWU = false>
+LSA_HD void ntt_group_fp(double (&v)[1 << RHO], bool inverse, const double* tw /* limb's table */, int s_base, unsigned G, double q, double qinv,
+                         bool scale_here, double sc0, double sc1, bool long_pass) {
+    constexpr int E = 1 << RHO;
+    if (!inverse) {
 #pragma unroll
-                for (int k = 0; k < (1 << j); k++) ntt_load_pair(tws + 2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, (unsigned)G), w[k], ws[k]);
+        for (int j = 0; j < RHO; j++) {
+            const int half = E >> (j + 1);
+            const int s = s_base + j;
+            double w[E / 2];   // this stage's 2^j twiddles: one 8-byte (j = 0) or 2^(j-1) 16-byte loads
+            if (TWU) {   // wave-uniform position: scalar loads
 #pragma unroll
-                for (int e = 0; e < E; e++) {
-                    if ((e & half) == 0) {
-                        const int k = e >> (RHO - j);
+                for (int k = 0; k < (1 << j); k++) w[k] = LSA_CONST_PTR(double, tw + (1LL << s))[ntt_tw_pos_fp(s, j, G, k)];
+            } else {
+                ntt_load_tw_fp(tw + (1LL << s), s, j, G, w);
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if ((e & half) == 0) {
 #if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)   // diagnostic build: constant twiddle (wrong results, same arithmetic)
-                        const u64 wk = (u64)(G + 2 * k + 3), wsk = (u64)(G + 2 * k + 5) << 40;
+                    const double T = fp_modmul(v[e + half], (double)(G + j + 3), q, qinv);
 #else
-                        const u64 wk = w[k], wsk = ws[k];
+                    const double T = fp_modmul(v[e + half], w[e >> (RHO - j)], q, qinv);
 #endif
-#if defined(LSA_NTT_EXACT_BFLY)   // Harvey's form: values in [0, 4q), exact quotient
-                        u64 U = csub(v[e], q2);
-                        u64 T = shoup_mul_lazy(v[e + half], wk, wsk, q);
-                        v[e] = U + T;
-                        v[e + half] = sub64(U + q2, T);
-#else                             // values in [0, 8q), product in [0, 4q) (modarith.h, shoup_mul_approx)
-                        u64 U = csub_sign(v[e], nq4);
-                        u64 T = shoup_mul_approx(v[e + half], wk, wsk, nq);
-                        LSA_EMU_CHECK(v[e] < 2 * q4 && U < q4 && T < q4);   // the range invariants, checked by the CPU replay
-                        v[e] = U + T;
-                        v[e + half] = sub64(U + q4, T);
-#endif
-                    }
+                    const double U = v[e];
+                    LSA_EMU_CHECK(__builtin_fabs(U) < 2251799813685248.0 && __builtin_fabs(v[e + half]) < 2251799813685248.0);   // 2^51: the engine's exactness bound
+                    v[e] = U + T;          // |.| grows by < 1.1q per stage: <= 10.9q < 2^51 over a 9-stage pass
+                    v[e + half] = U - T;
                 }
             }
-        } else {
+        }
+        if (long_pass) {   // longer (single-pass) transforms: back to |.| <= q/2+1 after every sub-pass (< 4q + 4.4q inside one)
 #pragma unroll
-            for (int j = RHO - 1; j >= 0; j--) {
-                const int half = E >> (j + 1);
-                const int s = a.s_lo + sig0 + j;
-                if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
+            for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], q, qinv);
+        }
+    } else {
 #pragma unroll
-                    for (int e = 0; e < half; e++) {
-                        u64 U = v[e], V = v[e + half];   // both in [0,2q) (exact form) / [0,4q); the exact product lands in [0,2q)
-                        v[e] = shoup_mul_lazy(U + V, sc0, sc0s, q);
-#if defined(LSA_NTT_EXACT_BFLY)
-                        v[e + half] = shoup_mul_lazy(sub64(U + q2, V), sc1, sc1s, q);
-#else
-                        v[e + half] = shoup_mul_lazy(sub64(U + q4, V), sc1, sc1s, q);
-#endif
-                    }
-                    continue;
+        for (int j = RHO - 1; j >= 0; j--) {
+            const int half = E >> (j + 1);
+            const int s = s_base + j;
+            if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
+#pragma unroll
+                for (int e = 0; e < half; e++) {
+                    const double U = v[e], V = v[e + half];
+                    v[e] = fp_modmul(U + V, sc0, q, qinv);
+                    v[e + half] = fp_modmul(U - V, sc1, q, qinv);
                 }
-                const u64* tws = tw + 2 * (1LL << s);
-                u64 w[E / 2], ws[E / 2];
+                continue;
+            }
+            double w[E / 2];
+            if (TWU) {   // wave-uniform position: scalar loads
 #pragma unroll
-                for (int k = 0; k < (1 << j); k++) ntt_load_pair(tws + 2 * ntt_tw_u_int(s, j, k) + 2u * ntt_tw_v_int(j, (unsigned)G), w[k], ws[k]);
+                for (int k = 0; k < (1 << j); k++) w[k] = LSA_CONST_PTR(double, tw + (1LL << s))[ntt_tw_pos_fp(s, j, G, k)];
+            } else {
+                ntt_load_tw_fp(tw + (1LL << s), s, j, G, w);
+            }
 #pragma unroll
-                for (int e = 0; e < E; e++) {
-                    if ((e & half) == 0) {
-                        const int k = e >> (RHO - j);
-                        u64 U = v[e], V = v[e + half];
-#if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)
-                        const u64 wk = (u64)(G + 2 * k + 3), wsk = (u64)(G + 2 * k + 5) << 40;
-#else
-                        const u64 wk = w[k], wsk = ws[k];
-#endif
-#if defined(LSA_NTT_EXACT_BFLY)   // both in [0,2q)
-                        v[e] = csub(U + V, q2);
-                        v[e + half] = shoup_mul_lazy(sub64(U + q2, V), wk, wsk, q);
-#else                             // both in [0,4q)
-                        LSA_EMU_CHECK(U < q4 && V < q4);
-                        v[e] = csub_sign(U + V, nq4);
-                        v[e + half] = shoup_mul_approx(sub64(U + q4, V), wk, wsk, nq);
-                        LSA_EMU_CHECK(v[e] < q4 && v[e + half] < q4);
-#endif
-                    }
+            for (int e = 0; e < E; e++) {
+                if ((e & half) == 0) {
+                    const double U = v[e], V = v[e + half];
+                    v[e] = U + V;   // sums at most double per stage: < 16 * 1.1q inside a sub-pass
+                    v[e + half] = fp_modmul(U - V, w[e >> (RHO - j)], q, qinv);
                 }
             }
         }
 #pragma unroll
-        for (int e = 0; e < E; e++) lds[LIN ? ad0 + e * adst : lds_addr(lbase + (e << beta0))] = v[e];
+        for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], q, qinv);  // back to |.| <= q/2+1 before the next sub-pass
     }
 }
 
@@ -671,60 +823,7 @@ LSA_HD void ntt_phase_sub_fp(const NttPassArgs& a, const NttBlockCtx& bc, int ti
         int r = (lbase >> a.lambda) & ((1 << a.mu) - 1);
         int H = ntt_hi_index(a, bc.tile, lbase);
         int G = (H << sig0) + (r >> (a.mu - sig0));
-        if (!a.inverse) {
-#pragma unroll
-            for (int j = 0; j < RHO; j++) {
-                const int half = E >> (j + 1);
-                const int s = a.s_lo + sig0 + j;
-                double w[E / 2];   // this stage's 2^j twiddles: one 8-byte (j = 0) or 2^(j-1) 16-byte loads
-                ntt_load_tw_fp(tw + (1LL << s), s, j, (unsigned)G, w);
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    if ((e & half) == 0) {
-#if defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS)   // diagnostic build: constant twiddle (wrong results, same arithmetic)
-                        const double T = fp_modmul(v[e + half], (double)(G + j + 3), q, qinv);
-#else
-                        const double T = fp_modmul(v[e + half], w[e >> (RHO - j)], q, qinv);
-#endif
-                        const double U = v[e];
-                        LSA_EMU_CHECK(__builtin_fabs(U) < 2251799813685248.0 && __builtin_fabs(v[e + half]) < 2251799813685248.0);   // 2^51: the engine's exactness bound
-                        v[e] = U + T;          // |.| grows by < 1.1q per stage: <= 10.9q < 2^51 over a 9-stage pass
-                        v[e + half] = U - T;
-                    }
-                }
-            }
-            if (a.mu > 9) {   // longer (single-pass) transforms: back to |.| <= q/2+1 after every sub-pass (< 4q + 4.4q inside one)
-#pragma unroll
-                for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], q, qinv);
-            }
-        } else {
-#pragma unroll
-            for (int j = RHO - 1; j >= 0; j--) {
-                const int half = E >> (j + 1);
-                const int s = a.s_lo + sig0 + j;
-                if (j == 0 && scale_here) {   // last stage of the whole transform: N^-1 folded into both outputs
-#pragma unroll
-                    for (int e = 0; e < half; e++) {
-                        const double U = v[e], V = v[e + half];
-                        v[e] = fp_modmul(U + V, sc0, q, qinv);
-                        v[e + half] = fp_modmul(U - V, sc1, q, qinv);
-                    }
-                    continue;
-                }
-                double w[E / 2];
-                ntt_load_tw_fp(tw + (1LL << s), s, j, (unsigned)G, w);
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    if ((e & half) == 0) {
-                        const double U = v[e], V = v[e + half];
-                        v[e] = U + V;   // sums at most double per stage: < 16 * 1.1q inside a sub-pass
-                        v[e + half] = fp_modmul(U - V, w[e >> (RHO - j)], q, qinv);
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], q, qinv);  // back to |.| <= q/2+1 before the next sub-pass
-        }
+        ntt_group_fp<RHO>(v, a.inverse != 0, tw, a.s_lo + sig0, (unsigned)G, q, qinv, scale_here, sc0, sc1, a.mu > 9);
 #pragma unroll
         for (int e = 0; e < E; e++) lds[LIN ? ad0 + e * adst : lds_addr(lbase + (e << beta0))] = d_to_bits(v[e]);
     }

@@ -19,7 +19,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 def emu():
     so = os.path.join(CSRC, "libls_emu.so")
     srcs = [os.path.join(CSRC, f) for f in ("emu_ntt.cpp", "tables.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("ntt_core.h", "ntt_plan.h", "modarith.h", "tables.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("ntt_core.h", "ntt_r16.h", "ntt_plan.h", "modarith.h", "tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-DLSA_EMULATE"] + os.environ.get("LSA_EXTRA_FLAGS", "").split() + ["-o", so] + srcs)
     L = ctypes.CDLL(so)
@@ -71,6 +71,22 @@ def test_fp64_engine_matches_oracle(emu, logn, tau):
     _check(emu, logn, tau, mods, fp64=1)
     _check(emu, logn, tau, mods, fp64=0)
     _check(emu, logn, tau, mods, fp64=3)   # the interleaved workgroup order of mixed-engine launches
+
+
+@pytest.mark.parametrize("logn", [15, 16, 17])
+def test_radix16_squared_passes_match_oracle(emu, logn):
+    """the 8-stage passes of two-pass plans through ntt_r16.h (both passes at N = 2^16, the second at 2^15, the first at 2^17;
+    the other pass of those rings stays on the staged kernel): both engines, forward and inverse, raw FP64 hand-off"""
+    D = params.CKKS_DEFAULT[65536]
+    B = params.CKKS_BOOTSTRAP_65536
+    if logn == 17:
+        P = params.ckks_n17_chain()
+        mods = [P["q"][0], P["q"][1], P["p"][0]]
+    else:
+        mods = [D["q"][1], B["q"][10], B["q"][0], B["p"][0]]   # 46- and 39-bit (FP64 engine), 60- and 61-bit (integer engine)
+    _check(emu, logn, 12, mods, fp64=4 | 1)
+    _check(emu, logn, 12, mods, fp64=4)
+    _check(emu, logn, 12, mods, fp64=4 | 3)
 
 
 def test_skipped_rows_get_no_workgroups(emu):
