@@ -8,9 +8,11 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <vector>
 
 namespace lsa {
 
@@ -46,8 +48,17 @@ class BufPool {
             }
         }
         *cap_words = words;
-        return static_cast<uint64_t*>(ops_.alloc(words * sizeof(uint64_t), device_, pinned_));
+        try {
+            return static_cast<uint64_t*>(ops_.alloc(words * sizeof(uint64_t), device_, pinned_));
+        } catch (...) {
+            // out of memory while this handle may be sitting on gigabytes of reclaimable pooled buffers (every lane of the
+            // device keeps its own, up to the cap): give them back and try once more before failing
+            if (on_pressure) on_pressure();
+            else trim(0);
+            return static_cast<uint64_t*>(ops_.alloc(words * sizeof(uint64_t), device_, pinned_));
+        }
     }
+    std::function<void()> on_pressure;   // set by the owner: frees what the sibling pools of this device hold
     void give(size_t cap_words, uint64_t* p) {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -115,8 +126,21 @@ class LanePools {
     BufPool& get(std::map<int, std::unique_ptr<BufPool>>& m, int k, int device, bool pinned, size_t cap) {
         std::lock_guard<std::mutex> lk(mu_);
         auto it = m.find(k);
-        if (it == m.end()) it = m.emplace(k, std::make_unique<BufPool>(device, pinned, ops_, cap)).first;
+        if (it == m.end()) {
+            it = m.emplace(k, std::make_unique<BufPool>(device, pinned, ops_, cap)).first;
+            it->second->on_pressure = [this, device, pinned]() { trim_device(device, pinned); };
+        }
         return *it->second;
+    }
+    // every pooled buffer of one kind on one device (all lanes): called by a pool whose allocation failed
+    void trim_device(int device, bool pinned) {
+        std::vector<BufPool*> victims;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (auto& kv : (pinned ? pin_ : dev_))
+                if (kv.second->device() == device) victims.push_back(kv.second.get());
+        }
+        for (BufPool* p : victims) p->trim(0);
     }
     BufAllocator ops_;
     size_t max_dev_, max_pin_;

@@ -159,9 +159,11 @@ static bool ntt_launch_r16(const NttPassArgs& a, int npass, bool fused, long lon
     const bool pro = fused && a.fz_pro && a.s_lo == 0, epi = fused && a.fz_epi && a.final_reduce;
     const size_t lds_bytes = (size_t)LSA_R16_LDS_WORDS * sizeof(u64);
     const dim3 grid((unsigned)nblocks), block(LSA_R16_THREADS);
-    static const bool pro_enabled = [] {   // A/B: the fused-prologue first pass on the staged kernel
+    // the two-operand prologue stays on the staged kernel: with 32 eight-byte loads per thread in front of the first radix
+    // group the register form measured 628 us per launch against 469 (profiles/r03/ab_r16_kernel_stats.log); LSA_R16_PRO=1 for A/B
+    static const bool pro_enabled = [] {
         const char* e = getenv("LSA_R16_PRO");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     if (a.lambda) {
         if (epi || (pro && !pro_enabled)) return false;   // (a first pass is never the last one of a two-pass plan)

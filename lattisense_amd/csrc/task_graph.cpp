@@ -216,8 +216,92 @@ void TaskGraph::validate_structure() const {
             const DataType k = c.input_nodes[1]->datum_type;
             if (k != TYPE_RELIN_KEY && k != TYPE_GALOIS_KEY && k != TYPE_SWITCH_KEY) bad(c, "second operand " + c.input_nodes[1]->id + " is not a key");
         }
+        // Relations between an operator's operands and its result.  The runtime sizes the result slab from the result's
+        // declared level / degree and launches over the first operand's rows (task_runtime.hip, run_gpu_bucket): a file
+        // that declares, say, an `add` whose result is lower than its operands, or a second operand of lower level or
+        // degree, would make a kernel write or read past a slab.  What the frontend emits always satisfies these
+        // (frontend/custom_task.py:971-1371: results are created from the operands' level and degree).
+        const DatumNode::FheProperty& a = *c.input_nodes[0]->fhe_prop;
+        const DatumNode::FheProperty& r = *c.output_nodes[0]->fhe_prop;
+        auto is_ct = [](const DatumNode* d) { return d->datum_type == TYPE_CIPHERTEXT; };
+        auto is_pt = [](const DatumNode* d) { return d->datum_type == TYPE_PLAINTEXT; };
+        auto ringt = [](const DatumNode* d) { return d->fhe_prop->p && d->fhe_prop->p->is_ringt; };
+        auto same_ct = [&](const DatumNode* d, const char* what) {
+            if (d->fhe_prop->level != a.level || d->fhe_prop->degree != a.degree)
+                bad(c, std::string(what) + " " + d->id + " has level/degree " + std::to_string(d->fhe_prop->level) + "/" + std::to_string(d->fhe_prop->degree) +
+                           ", the first operand " + std::to_string(a.level) + "/" + std::to_string(a.degree));
+        };
+        auto plain_ok = [&](const DatumNode* d) {   // a full plaintext lives at the ciphertext's level; a ring-t one is a single limb
+            if (!ringt(d) && d->fhe_prop->level != a.level)
+                bad(c, "plaintext " + d->id + " is at level " + std::to_string(d->fhe_prop->level) + ", the ciphertext at " + std::to_string(a.level));
+        };
+        auto key_ok = [&](const DatumNode* d) {
+            if (d->fhe_prop->level < a.level) bad(c, "key " + d->id + " was exported at level " + std::to_string(d->fhe_prop->level) + ", below the ciphertext's " + std::to_string(a.level));
+        };
+        auto result = [&](int level, int degree) {
+            if (r.level != level || r.degree != degree)
+                bad(c, "result " + c.output_nodes[0]->id + " is declared at level/degree " + std::to_string(r.level) + "/" + std::to_string(r.degree) +
+                           ", the operation produces " + std::to_string(level) + "/" + std::to_string(degree));
+        };
+        switch (c.op()) {
+            case OperationType::ADD:
+            case OperationType::SUB:
+                if (n == 2 && is_ct(c.input_nodes[1])) same_ct(c.input_nodes[1], "second operand");
+                else if (n == 2 && is_pt(c.input_nodes[1])) plain_ok(c.input_nodes[1]);
+                else if (n == 2) bad(c, "second operand " + c.input_nodes[1]->id + " is neither a ciphertext nor a plaintext");
+                result(a.level, a.degree);
+                break;
+            case OperationType::NEGATE: result(a.level, a.degree); break;
+            case OperationType::MULTIPLY:
+                if (n == 2 && is_pt(c.input_nodes[1])) {
+                    plain_ok(c.input_nodes[1]);
+                    result(a.level, a.degree);
+                } else {
+                    if (n == 2 && !is_ct(c.input_nodes[1])) bad(c, "second operand " + c.input_nodes[1]->id + " is neither a ciphertext nor a plaintext");
+                    if (n == 2) same_ct(c.input_nodes[1], "second operand");
+                    if (a.degree != 1) bad(c, "ciphertext multiply expects degree-1 operands");
+                    result(a.level, 2);
+                }
+                break;
+            case OperationType::RELINEARIZE:
+                if (a.degree != 2) bad(c, "relinearize expects a degree-2 ciphertext");
+                key_ok(c.input_nodes[1]);
+                result(a.level, 1);
+                break;
+            case OperationType::RESCALE:
+                if (a.level < 1) bad(c, "rescale needs level >= 1");
+                result(a.level - 1, a.degree);
+                break;
+            case OperationType::DROP_LEVEL:
+                if (r.level >= a.level) bad(c, "drop_level must lower the level");
+                result(r.level, a.degree);
+                break;
+            case OperationType::ROTATE_COL:
+            case OperationType::ROTATE_ROW:
+                if (a.degree != 1) bad(c, "rotation expects a degree-1 ciphertext");
+                key_ok(c.input_nodes[1]);
+                result(a.level, 1);
+                break;
+            case OperationType::MAC_WO_PARTIAL_SUM:
+            case OperationType::MAC_W_PARTIAL_SUM:
+                for (size_t i = 1; i < n; i++) {
+                    const DatumNode* d = c.input_nodes[i];
+                    if (is_ct(d)) same_ct(d, "operand");
+                    else if (is_pt(d)) plain_ok(d);
+                    else bad(c, "operand " + d->id + " is neither a ciphertext nor a plaintext");
+                }
+                result(a.level, a.degree);
+                break;
+            case OperationType::BOOTSTRAP:
+                if (a.degree != 1 || r.degree != 1) bad(c, "bootstrap expects and produces degree-1 ciphertexts");
+                break;
+            default: break;
+        }
     }
-    const int64_t n_q = parameter.contains("q") ? (int64_t)parameter["q"].size() : INT32_MAX;
+    // levels index the chain the context is built on: the first max_level+1 primes of `q` (frontend/parameter.json lists 30
+    // primes for CKKS n=65536 under max_level 33, SURVEY App. A: what exists bounds it the other way)
+    int64_t n_q = parameter.contains("q") ? (int64_t)parameter["q"].size() : INT32_MAX;
+    if (parameter.contains("max_level") && parameter["max_level"].kind == mjson::Value::Int) n_q = std::min<int64_t>(n_q, parameter["max_level"].as_int() + 1);
     for (auto& kv : data) {
         const DatumNode& d = kv.second;
         if (d.fhe_prop && (d.fhe_prop->level < 0 || d.fhe_prop->level >= n_q || d.fhe_prop->degree < 0 || d.fhe_prop->degree > 2))

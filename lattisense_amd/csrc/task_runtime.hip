@@ -1404,12 +1404,15 @@ ExecutorFunc frontend_export() {
                 });
                 break;
             }
-            default:
-                // custom input data (TYPE_CUSTOM: e.g. a message a custom "encode" node turns into a plaintext) never reaches the
-                // device: the opaque caller handle is handed through to the custom executors that consume it
-                // (cxx_abi_bridge_executors.h does the same with CustomData)
+            case TYPE_CUSTOM:
+                // custom input data (e.g. a message a custom "encode" node turns into a plaintext) never reaches the device: the
+                // opaque caller handle is handed through to the custom executors that consume it
+                // (cxx_abi_bridge_executors.h:212-220 does the same with CustomData)
                 output = inputs.at(in->index);
                 break;
+            default:   // an unknown or garbled type must not reach downstream any_casts (the reference throws here too, ibid.)
+                throw std::runtime_error("Unsupported data type " + std::to_string((int)in->datum_type) + " for input '" + in->id + "' (datum " +
+                                         std::to_string(in->index) + ")");
         }
     };
 }

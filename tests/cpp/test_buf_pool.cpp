@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <set>
+#include <stdexcept>
 
 #include "../../lattisense_amd/csrc/buf_pool.h"
 
@@ -18,8 +19,11 @@ struct Rec {
 };
 std::map<void*, Rec> live;
 int n_alloc = 0, n_free = 0, wrong_device_free = 0;
+size_t budget = (size_t)-1, in_use = 0;   // case 7: a device that runs out of memory
 
 void* fake_alloc(size_t bytes, int device, bool pinned) {
+    if (in_use + bytes > budget) throw std::runtime_error("out of memory");
+    in_use += bytes;
     void* p = malloc(16);
     live[p] = Rec{device, pinned, bytes};
     n_alloc++;
@@ -29,6 +33,7 @@ void fake_release(void* p, int device, bool pinned) {
     auto it = live.find(p);
     assert(it != live.end());
     if (it->second.device != device || it->second.pinned != pinned) wrong_device_free++;
+    in_use -= it->second.bytes;
     live.erase(it);
     free(p);
     n_free++;
@@ -94,6 +99,27 @@ int main() {
         uint64_t* z = pools.device_pool(0, 0).take(1000, &cap);
         CHECK(live.at(z).device == 0);
         pools.device_pool(0, 0).give(cap, z);
+        // 7. out of memory with reclaimable buffers pooled on the SAME device (other lane): they are given back and the
+        //    allocation is retried once; a request that cannot fit even then still fails
+        pools.trim_all();
+        budget = in_use + 8 * 1000;
+        uint64_t* l0 = pools.device_pool(5, 0).take(600, &cap);
+        pools.device_pool(5, 0).give(cap, l0);                       // 4800 bytes pooled on lane 0
+        uint64_t* other = pools.device_pool(6, 0).take(100, &cap);   // another device: must survive the pressure trim
+        pools.device_pool(6, 0).give(cap, other);
+        uint64_t* l1 = pools.device_pool(5, 1).take(900, &cap);      // 7200 bytes: only fits once lane 0's buffer is freed
+        CHECK(live.at(l1).device == 5 && pools.device_pool(5, 0).free_count() == 0);
+        CHECK(pools.device_pool(6, 0).free_count() == 1);
+        bool threw = false;
+        try {
+            size_t c2;
+            pools.device_pool(5, 0).take(2000, &c2);
+        } catch (const std::exception&) {
+            threw = true;
+        }
+        CHECK(threw);
+        pools.device_pool(5, 1).give(cap, l1);
+        budget = (size_t)-1;
     }
     // destruction frees everything that was pooled, each on its owning device
     CHECK(live.empty());

@@ -95,6 +95,42 @@ def _mutations(g, rng):
     m("two_producers", lambda h: [c.__setitem__("outputs", list(h["compute"][first_c]["outputs"])) for c in h["compute"].values()])
     m("custom_without_type", lambda h: (h["compute"][first_c].__setitem__("is_custom", True), h["compute"][first_c].pop("type")))
     m("custom_flag_string", lambda h: h["compute"][first_c].__setitem__("is_custom", "yes"))
+    # operand / result relations: what the runtime sizes its slabs and launches from (task_graph.cpp, validate_structure)
+    def fhe_nodes(h):
+        return [c for _, c in sorted(h["compute"].items(), key=lambda kv: int(kv[0])) if not c.get("is_custom")]
+
+    def first_of(h, *types):
+        for c in fhe_nodes(h):
+            if c["type"] in types:
+                return c
+        return None
+
+    def out_of(h, c):
+        return h["data"][str(c["outputs"][0])]
+
+    def in_of(h, c, i=0):
+        return h["data"][str(c["inputs"][i])]
+
+    any_op = first_of(g, "add", "sub", "neg", "mult", "relin", "rotate_col", "rotate_row", "cmp_sum", "cmpac_sum")
+    if any_op:
+        ty = any_op["type"]
+        m("result_level_lower_than_operands", lambda h: out_of(h, first_of(h, ty)).__setitem__("level", max(0, in_of(h, first_of(h, ty))["level"] - 1)
+                                                                                                if in_of(h, first_of(h, ty))["level"] > 0 else in_of(h, first_of(h, ty))["level"] + 1))
+        m("result_degree_wrong", lambda h: out_of(h, first_of(h, ty)).__setitem__("degree", (out_of(h, first_of(h, ty))["degree"] + 1) % 3))
+    two_ct = next((c for c in fhe_nodes(g) if c["type"] in ("add", "sub", "mult") and len(c["inputs"]) == 2 and g["data"][str(c["inputs"][1])]["type"] == "ct"
+                   and g["data"][str(c["inputs"][1])]["level"] > 0 and str(c["inputs"][1]) != str(c["inputs"][0])), None)
+    if two_ct:
+        idx = str(two_ct["inputs"][1])
+        m("second_operand_lower_level", lambda h: h["data"][idx].__setitem__("level", h["data"][idx]["level"] - 1))
+    rs_node = first_of(g, "rescale")
+    if rs_node:
+        m("rescale_keeps_level", lambda h: out_of(h, first_of(h, "rescale")).__setitem__("level", in_of(h, first_of(h, "rescale"))["level"]))
+    keyed = first_of(g, "relin", "rotate_col", "rotate_row")
+    if keyed and in_of(g, keyed)["level"] > 0:
+        kt = keyed["type"]
+        m("key_below_ciphertext_level", lambda h: in_of(h, first_of(h, kt), 1).__setitem__("level", in_of(h, first_of(h, kt))["level"] - 1))
+    if g["parameter"].get("max_level") is not None and len(g["parameter"].get("q", [])) > 1:
+        m("level_beyond_max_level", lambda h: (h["parameter"].__setitem__("max_level", 0), None))
     # a cycle between the first two compute nodes
     if len(g["compute"]) >= 2:
         a, b = sorted(g["compute"], key=int)[:2]
