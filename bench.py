@@ -246,7 +246,8 @@ def run_task_workload(args):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": name + " through run_fhe_gpu_task (host buffers, PCIe-inclusive)", "n_op": n_op,
-                   "gpu_nodes": st["gpu_nodes"], "batched_launch_groups": st["gpu_batches"]},
+                   "gpu_nodes": st["gpu_nodes"], "batched_launch_groups": st["gpu_batches"],
+                   "keys_last_run": t.last_run_keys()},
         "roofline": None, "cpu_baseline": None}), flush=True)
 
 

@@ -129,6 +129,24 @@ int lsa_frontend_bind(fhe_task_handle handle);
  * (device, lane): one task handle may be run on any gpu_device, one run at a time (reference: README.md:195-202) */
 int lsa_task_trim_pools(fhe_task_handle handle);
 
+/* Multi-device execution behind run_fhe_gpu_task (the reference's only multi-GPU mode is one run per device,
+ * README.md:195-202, which exports and uploads every key once per device and run).  With a device list set, a run whose graph
+ * splits into independent subgraphs deals them out to the listed devices -- one pair of execution lanes per entry; an index may
+ * repeat (two logical shards on one device) -- exports and uploads every evaluation key ONCE on the first device and copies it
+ * device-to-device to the others.  Results are imported as always.  n_devices = 0 clears the list.  With a list set (or
+ * gpu_device = -1: every visible device) the gpu_device argument of run_fhe_gpu_task is ignored. */
+int lsa_task_set_devices(fhe_task_handle handle, const int* device_ids, int n_devices);
+int lsa_task_last_run_shards(fhe_task_handle handle, int* n_shards, int* n_chunks, int* key_peer_copies);
+
+/* Evaluation keys stay resident on the device(s) across run() calls: a run whose export executor yields the same caller
+ * handle and the same fingerprint (shape + three sampled words of every limb of the exported C struct) for a key datum reuses
+ * the converted device copy instead of staging, uploading and converting it again (the reference re-exports and re-uploads every
+ * key on every run, cxx_sdk_v2/cxx_argument.h:178-260).  A regenerated key or another key object is detected and replaces the
+ * copy; a caller that rewrites a key in place must call lsa_task_drop_keys (frees the device copies; the next run uploads).
+ * LSA_NO_KEY_CACHE=1 in the environment restores upload-per-run. */
+int lsa_task_drop_keys(fhe_task_handle handle);
+int lsa_task_last_run_keys(fhe_task_handle handle, int* uploaded, int* reused);
+
 /* introspection used by tests and INTEGRATION.md examples */
 int lsa_task_counts(fhe_task_handle handle, int* n_data, int* n_compute, int* n_inputs, int* n_outputs);
 /* number of batched launch groups vs. compute nodes in the last run (how much graph-level batching happened) */

@@ -115,7 +115,8 @@ class LanePools {
         : ops_(ops), max_dev_(max_free_dev_bytes), max_pin_(max_free_pin_bytes) {}
     BufPool& device_pool(int device, int lane) { return get(dev_, key(device, lane), device, false, max_dev_); }
     BufPool& pinned_pool(int device) { return get(pin_, device, device, true, max_pin_); }
-    static int key(int device, int lane) { return 2 * device + lane; }
+    static int key(int device, int lane) { return 64 * device + lane; }   // lanes of one device are numbered across its shards (shard_plan.h)
+    static int device_of(int key) { return key / 64; }
     void trim_all() {
         std::lock_guard<std::mutex> lk(mu_);
         for (auto& kv : dev_) kv.second->trim(0);

@@ -27,6 +27,7 @@
 
 #include "buf_pool.h"
 #include "lsa_internal.h"
+#include "shard_plan.h"
 #include "task_graph.h"
 
 namespace lsa {
@@ -187,6 +188,13 @@ const char* op_name(OperationType op) {
     }
 }
 
+// which (device, lane) the calling host thread is enqueueing on: every shard of a run has its own thread (run()), a handle runs
+// one run() at a time, so the pools / temporaries a helper touches follow from the thread it is called on
+struct ExecTls {
+    int device = 0, lane = 0;
+};
+thread_local ExecTls tls_exec;
+
 bool is_plain_node(const DatumNode* d) { return d->datum_type == TYPE_PLAINTEXT; }
 bool is_ringt_node(const DatumNode* d) { return d->fhe_prop && d->fhe_prop->p && d->fhe_prop->p->is_ringt; }
 
@@ -252,19 +260,52 @@ struct fhe_task_handle_st {
     LanePools pools{BufAllocator{hip_buf_alloc, hip_buf_release}, pool_cap_bytes("LSA_POOL_MAX_DEV_GIB", 48.0),
                     pool_cap_bytes("LSA_POOL_MAX_PIN_GIB", 16.0)};   // declared first: destroyed last
     std::mutex run_mu;
-    int cur_device = 0, cur_lane = 0;
-    std::shared_ptr<Slab> dslab(size_t words) { return std::make_shared<Slab>(pools.device_pool(cur_device, cur_lane), words); }
-    std::shared_ptr<Slab> pslab(size_t words) { return std::make_shared<Slab>(pools.pinned_pool(cur_device), words); }
+    std::shared_ptr<Slab> dslab(size_t words) { return std::make_shared<Slab>(pools.device_pool(tls_exec.device, tls_exec.lane), words); }
+    std::shared_ptr<Slab> pslab(size_t words) { return std::make_shared<Slab>(pools.pinned_pool(tls_exec.device), words); }
+    std::vector<int> devices_;   // lsa_task_set_devices: the shards of a run (a device may repeat); empty = the run's gpu_device alone
+    // Evaluation keys stay on the device across run() calls (SURVEY f3 "persistent state"; the reference re-exports and
+    // re-uploads them every run, cxx_sdk_v2/cxx_argument.h:178-260): per (device, key datum) the converted key is kept together
+    // with the caller's handle and a fingerprint of the exported C struct (shape + three words of every limb).  A run whose
+    // export yields the same handle and fingerprint skips staging, upload and conversion; anything else (another key object, a
+    // regenerated key) replaces the entry.  CONTRACT: a caller that rewrites a key IN PLACE so that the sampled words stay the
+    // same must call lsa_task_drop_keys.  lsa_task_drop_keys / release free the device copies.
+    struct CachedKey {
+        const void* handle = nullptr;
+        uint64_t fingerprint = 0;
+        KeyP key;
+    };
+    std::map<std::pair<int, NodeIndex>, CachedKey> key_cache;   // touched by the thread that runs the shared levels / the fan-out only
+    bool keep_keys = getenv("LSA_NO_KEY_CACHE") == nullptr;
+    int last_key_uploads = 0, last_key_hits = 0;
+    static uint64_t ksk_fingerprint(const CKeySwitchKey* k, int n) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)k->n_public_key;
+        auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001B3ull + (h >> 29); };
+        for (int d = 0; d < k->n_public_key; d++) {
+            const CPublicKey& pk = k->public_keys[d];
+            mix((uint64_t)pk.level * 131 + (uint64_t)pk.degree);
+            for (int p = 0; p <= pk.degree; p++)
+                for (int j = 0; j < pk.polys[p].n_component; j++) {
+                    const uint64_t* w = pk.polys[p].components[j].data;
+                    mix(w[0]);
+                    mix(w[n / 2]);
+                    mix(w[n - 1]);
+                }
+        }
+        return h;
+    }
     TaskGraph g;
     std::vector<std::vector<ComputeNode*>> levels;
     std::vector<std::vector<ComputeNode*>> shared_levels;                  // key export/load: before every chunk
     std::vector<std::vector<std::vector<ComputeNode*>>> chunk_levels;      // [chunk][level] -> nodes; empty: not pipelined
-    std::map<int, std::unique_ptr<Context>> contexts;                      // key = 2*device + lane
+    std::map<int, std::unique_ptr<Context>> contexts;                      // key = LanePools::key(device, lane)
     std::map<int, hipStream_t> streams;
     std::map<int, std::vector<std::shared_ptr<Slab>>> pending_free_;   // temporaries still referenced by enqueued work, per (device, lane)
-    std::vector<std::shared_ptr<Slab>>& pending_free() { return pending_free_[LanePools::key(cur_device, cur_lane)]; }
-    int last_gpu_nodes = 0, last_gpu_batches = 0;
+    // (entries are created by run() before any shard thread starts: concurrent callers only look their own up)
+    std::vector<std::shared_ptr<Slab>>& pending_free() { return pending_free_.at(LanePools::key(tls_exec.device, tls_exec.lane)); }
+    std::atomic<int> last_gpu_nodes{0}, last_gpu_batches{0};
+    int last_shards = 1, last_chunks = 0, last_key_peer_copies = 0;
     double last_ms = 0;
+    std::mutex bootstrap_mu;
     struct BtDeleter {
         void operator()(Bootstrap* b) const { bootstrap_destroy(b); }
     };
@@ -272,6 +313,7 @@ struct fhe_task_handle_st {
 
     // bootstrapping plan from the task's `parameter` block (reference: gpu_wrapper.cu:86-117)
     Bootstrap& bootstrap_plan(Context& c, hipStream_t s) {
+        std::lock_guard<std::mutex> lk(bootstrap_mu);
         auto it = bootstrap_plans.find(&c);
         if (it != bootstrap_plans.end()) return *it->second;
         const mjson::Value& P = g.parameter;
@@ -312,13 +354,17 @@ struct fhe_task_handle_st {
         for (auto& kv : g.computes) levels[kv.second.sched_meta.top_level].push_back(&kv.second);
         for (auto& lv : levels)
             std::sort(lv.begin(), lv.end(), [](const ComputeNode* a, const ComputeNode* b) { return a->index < b->index; });
-        if (!getenv("LSA_NO_PIPELINE")) plan_pipeline();
+        if (!getenv("LSA_NO_PIPELINE")) plan_pipeline(1);
     }
 
     // Independent subgraphs = connected components of the compute nodes over the non-key data (evaluation keys are shared
     // read-only inputs).  Pipelining needs the simple shape every benchmark graph has: per chunk, CPU nodes only before
     // the loads and after the stores, and all stores in one level.
-    void plan_pipeline() {
+    int planned_shards_ = 0;
+    void plan_pipeline(int n_shards) {
+        planned_shards_ = n_shards;
+        shared_levels.clear();
+        chunk_levels.clear();
         auto is_key = [](const DatumNode* d) {
             return d->datum_type == TYPE_RELIN_KEY || d->datum_type == TYPE_GALOIS_KEY || d->datum_type == TYPE_SWITCH_KEY;
         };
@@ -367,7 +413,7 @@ struct fhe_task_handle_st {
         }
         const char* min_mib = getenv("LSA_PIPELINE_MIN_MIB");   // tests force the pipelined path on small graphs with 0
         if (in_bytes < (min_mib ? atof(min_mib) : 256.0) * 1048576.0) return;
-        const int nchunks = (int)std::min<size_t>(8, comps.size() / 2);
+        const int nchunks = plan_chunk_count(comps.size(), n_shards);
         std::unordered_map<const ComputeNode*, int> chunk_of;
         int ci = 0;
         for (auto& kv : comps) chunk_of[kv.second] = (int)((long long)ci++ * nchunks / (long long)comps.size());
@@ -401,13 +447,13 @@ struct fhe_task_handle_st {
     }
     ~fhe_task_handle_st() {
         for (auto& kv : streams) {
-            (void)hipSetDevice(kv.first / 2);
+            (void)hipSetDevice(LanePools::device_of(kv.first));
             (void)hipStreamDestroy(kv.second);
         }
     }
 
     Context& context(int device, int lane = 0) {
-        const int key = 2 * device + lane;
+        const int key = LanePools::key(device, lane);
         auto it = contexts.find(key);
         if (it != contexts.end()) {
             it->second->use_device();
@@ -452,7 +498,11 @@ struct fhe_task_handle_st {
             // Every operand is sized from the graph's fhe_prop downstream (gather / run_gpu_bucket): a C struct that disagrees
             // with the task's declaration would make those kernels read past the loaded slab, so it is refused here.
             auto bad = [&](const std::string& what) {
-                throw Error(LSA_ERR_ARG, "input '" + in->id + "' (datum " + std::to_string(in->index) + "): " + what);
+                // name the caller's datum: the C struct is the output of the export node inserted in front of this load
+                const DatumNode* orig = in;
+                if (!in->predecessors.empty() && in->predecessors[0]->op() == OperationType::EXPORT_TO_ABI && !in->predecessors[0]->input_nodes.empty())
+                    orig = in->predecessors[0]->input_nodes[0];
+                throw Error(LSA_ERR_ARG, "input '" + orig->id + "' (datum " + std::to_string(orig->index) + "): " + what);
             };
             if (in->datum_type == TYPE_CIPHERTEXT) {
                 auto ct = std::any_cast<std::shared_ptr<CCiphertext>>(cs);
@@ -495,6 +545,8 @@ struct fhe_task_handle_st {
             std::any keep;
             int level, beta, comp;
             size_t off;
+            const void* handle;
+            uint64_t fingerprint;
         };
         std::vector<KeyItem> keys;
         for (ComputeNode* node : key_nodes) {
@@ -529,6 +581,21 @@ struct fhe_task_handle_st {
                     LSA_REQUIRE(pk.polys[h].components && pk.polys[h].n_component == k.comp, "key-switch key: limb count differs between digits");
                     for (int j = 0; j < k.comp; j++)
                         LSA_REQUIRE(pk.polys[h].components[j].n == c.n && pk.polys[h].components[j].data, "key-switch key has a wrong ring degree");
+                }
+            }
+            // resident already?  (same caller handle behind the export node, same fingerprint of what it exported)
+            const DatumNode* orig = (!in->predecessors.empty() && !in->predecessors[0]->input_nodes.empty()) ? in->predecessors[0]->input_nodes[0] : in;
+            const std::any* hv = avail.count(orig->index) ? &avail.at(orig->index) : nullptr;
+            const std::shared_ptr<void>* hp = hv ? std::any_cast<std::shared_ptr<void>>(hv) : nullptr;
+            k.handle = hp ? hp->get() : nullptr;
+            k.fingerprint = ksk_fingerprint(k.ksk, c.n);
+            if (keep_keys) {
+                auto hit = key_cache.find({c.device, node->output_nodes[0]->index});
+                if (hit != key_cache.end() && hit->second.handle == k.handle && hit->second.fingerprint == k.fingerprint &&
+                    hit->second.key->key.level == k.level) {
+                    avail[node->output_nodes[0]->index] = hit->second.key;
+                    last_key_hits++;
+                    continue;
                 }
             }
             k.off = total;
@@ -617,6 +684,8 @@ struct fhe_task_handle_st {
             for (int j = 0; j < k.comp; j++) rm.mod_of[j] = (unsigned char)(j <= k.level ? j : c.p_mod(j - k.level - 1));
             launch_to_mont(c, dk->key.data, k.beta * 2 * k.comp, rm, s);
             avail[k.node->output_nodes[0]->index] = dk;
+            last_key_uploads++;
+            if (keep_keys) key_cache[{c.device, k.node->output_nodes[0]->index}] = CachedKey{k.handle, k.fingerprint, dk};
         }
         return hstage;
     }
@@ -1074,16 +1143,37 @@ struct fhe_task_handle_st {
     }
 
     // ---------------------------------------------------------------- run
+    // the devices a run is spread over: lsa_task_set_devices' list, else the caller's gpu_device (-1: every visible device)
+    std::vector<int> run_devices(int device) {
+        if (device >= 0 && devices_.empty()) return {device};
+        if (!devices_.empty()) return devices_;
+        int n = 0;
+        LSA_HIP(hipGetDeviceCount(&n));
+        LSA_REQUIRE(n >= 1, "no HIP device");
+        std::vector<int> all(n);
+        for (int i = 0; i < n; i++) all[i] = i;
+        return all;
+    }
+
     void run(CArgument* in_args, uint64_t n_in, CArgument* out_args, uint64_t n_out, progress_callback_t cb, void* user,
              int device) {
         std::lock_guard<std::mutex> run_lock(run_mu);   // one run at a time per handle (the graph state is shared)
         const auto t_start = std::chrono::steady_clock::now();
-        cur_device = device;
-        cur_lane = 0;
-        pending_free_[LanePools::key(device, 0)];   // both lanes' entries exist before any finisher thread looks them up
-        pending_free_[LanePools::key(device, 1)];
-        Context& c = context(device);
-        hipStream_t s = streams.at(2 * device);
+        const std::vector<int> devs = run_devices(device);
+        if (!getenv("LSA_NO_PIPELINE") && planned_shards_ != (int)devs.size()) plan_pipeline((int)devs.size());   // chunk count follows the shard count
+        // shards: one device + two lanes each; chunks of independent subgraphs are dealt out to them (shard_plan.h)
+        const ShardPlan plan = plan_shards(chunk_levels.empty() ? std::vector<int>{devs[0]} : devs, (int)chunk_levels.size());
+        const int up_dev = plan.upload_device();
+        // contexts, streams and the per-lane temporaries lists exist before any worker thread looks them up
+        for (const ShardPlan::Shard& sh : plan.shards)
+            for (int l = 0; l < 2; l++) {
+                pending_free_[LanePools::key(sh.device, sh.lane0 + l)];
+                if (!chunk_levels.empty() || l == 0) context(sh.device, sh.lane0 + l);
+            }
+        tls_exec.device = up_dev;
+        tls_exec.lane = 0;
+        Context& c = context(up_dev, 0);
+        hipStream_t s = streams.at(LanePools::key(up_dev, 0));
         // inputs: flatten every CArgument's handle array, consume in mega_ag.inputs order; all Galois-key data nodes share
         // the first Galois handle (cpu_task_utils.h:235-319)
         std::vector<void*> handles;
@@ -1124,14 +1214,21 @@ struct fhe_task_handle_st {
         const int total = (int)g.computes.size();
         int completed = 0;
         auto last_cb = std::chrono::steady_clock::now() - std::chrono::seconds(1);
-        last_gpu_nodes = last_gpu_batches = 0;
+        last_gpu_nodes = 0;
+        last_gpu_batches = 0;
+        last_shards = 1;
+        last_chunks = (int)chunk_levels.size();
+        last_key_peer_copies = 0;
+        last_key_uploads = last_key_hits = 0;
 
         const bool trace = getenv("LSA_TASK_TRACE") != nullptr;
         auto tick = [&]() { return std::chrono::steady_clock::now(); };
         auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
             return std::chrono::duration<double, std::milli>(tick() - t0).count();
         };
+        std::mutex progress_mu;   // the callback fires from whichever thread finished something (wrapper.h:39-40)
         auto progress = [&](size_t nodes_done) {
+            std::lock_guard<std::mutex> lk(progress_mu);
             completed += (int)nodes_done;
             const auto now = std::chrono::steady_clock::now();
             if (cb && (completed == total || now - last_cb >= std::chrono::milliseconds(100))) {
@@ -1139,10 +1236,12 @@ struct fhe_task_handle_st {
                 last_cb = now;
             }
         };
-        auto release_inputs = [&](const std::vector<ComputeNode*>& level) {
+        using Avail = std::unordered_map<NodeIndex, std::any>;
+        using Refs = std::unordered_map<NodeIndex, int>;
+        auto release_inputs = [](const std::vector<ComputeNode*>& level, Avail& av, Refs& rf) {
             for (ComputeNode* n : level)
                 for (auto* in : n->input_nodes)
-                    if (--refs[in->index] <= 0 && !in->is_input && !in->is_output) avail.erase(in->index);
+                    if (--rf[in->index] <= 0 && !in->is_input && !in->is_output) av.erase(in->index);
         };
         struct Split {
             std::vector<ComputeNode*> cpu, loads, stores;
@@ -1186,7 +1285,7 @@ struct fhe_task_handle_st {
             if (trace)
                 fprintf(stderr, "[lsa task] level: %zu nodes  load %.2f ms  gpu %.2f ms  store %.2f ms  cpu %.2f ms\n",
                         level.size(), t_load, t_gpu, t_store, t_cpu);
-            release_inputs(level);
+            release_inputs(level, avail, refs);
             if (!pending_free().empty()) {  // slabs whose last reference is dropped here are freed after their readers ran
                 LSA_HIP(hipStreamSynchronize(s));
                 pending_free().clear();
@@ -1197,104 +1296,224 @@ struct fhe_task_handle_st {
         if (chunk_levels.empty()) {
             for (auto& level : levels) run_level_sync(level);
         } else {
-            // shared evaluation keys first (lane 0); lane 1 waits for them on the device
+            // shared evaluation keys first: exported, uploaded and converted ONCE, on the first device of the list
             for (auto& level : shared_levels) run_level_sync(level);
-            Context& c1 = context(device, 1);
-            hipStream_t s1 = streams.at(2 * device + 1);
             LSA_HIP(hipStreamSynchronize(s));
+            last_shards = (int)plan.shards.size();
+            // ... then copied device-to-device to every other distinct device (shards of one device share its copy)
+            std::map<int, Avail> dev_avail;
+            dev_avail[up_dev] = avail;
+            if (plan.key_devices.size() > 1) {
+                std::vector<NodeIndex> key_idx;
+                std::vector<KeyP> key_src;
+                std::vector<void*> src;
+                std::vector<size_t> bytes;
+                for (auto& kv : avail)
+                    if (auto* kp = std::any_cast<KeyP>(&kv.second)) {
+                        key_idx.push_back(kv.first);
+                        key_src.push_back(*kp);
+                        src.push_back((*kp)->key.data);
+                        bytes.push_back((*kp)->slab->words * sizeof(u64));
+                    }
+                struct PeerOps {
+                    fhe_task_handle_st* self;
+                    const ShardPlan* plan;
+                    std::map<void*, std::shared_ptr<Slab>> slabs;
+                    int copies = 0;
+                    int lane0(int d) const {
+                        for (auto& sh : plan->shards)
+                            if (sh.device == d) return sh.lane0;
+                        return 0;
+                    }
+                    void* alloc(int d, size_t nbytes) {
+                        auto sl = std::make_shared<Slab>(self->pools.device_pool(d, lane0(d)), nbytes / sizeof(u64));
+                        slabs[sl->ptr] = sl;
+                        return sl->ptr;
+                    }
+                    void peer_copy(void* dst, int dd, const void* sp, int sd, size_t nbytes) {
+                        LSA_HIP(hipSetDevice(dd));
+                        int can = 0;
+                        if (hipDeviceCanAccessPeer(&can, dd, sd) == hipSuccess && can) {
+                            const hipError_t e = hipDeviceEnablePeerAccess(sd, 0);   // direct xGMI copies; already enabled is fine
+                            if (e != hipSuccess) (void)hipGetLastError();
+                        }
+                        LSA_HIP(hipMemcpyPeerAsync(dst, dd, sp, sd, nbytes, self->streams.at(LanePools::key(dd, lane0(dd)))));
+                        copies++;
+                    }
+                } ops{this, &plan, {}, 0};
+                // a peer copy made by an earlier run is still valid while the upload device's entry it was made from is
+                // (same handle and fingerprint): those keys are taken from the cache, the others are copied now
+                std::vector<char> cached(key_idx.size() * plan.key_devices.size(), 0);
+                if (keep_keys)
+                    for (size_t i = 1; i < plan.key_devices.size(); i++)
+                        for (size_t k = 0; k < key_idx.size(); k++) {
+                            auto up = key_cache.find({up_dev, key_idx[k]});
+                            auto pe = key_cache.find({plan.key_devices[i], key_idx[k]});
+                            cached[i * key_idx.size() + k] = up != key_cache.end() && pe != key_cache.end() && up->second.key == key_src[k] &&
+                                                             pe->second.handle == up->second.handle && pe->second.fingerprint == up->second.fingerprint;
+                        }
+                for (size_t i = 1; i < plan.key_devices.size(); i++) {
+                    const int d = plan.key_devices[i];
+                    std::vector<void*> src_d;
+                    std::vector<size_t> bytes_d;
+                    std::vector<size_t> which;
+                    for (size_t k = 0; k < key_idx.size(); k++)
+                        if (!cached[i * key_idx.size() + k]) {
+                            src_d.push_back(src[k]);
+                            bytes_d.push_back(bytes[k]);
+                            which.push_back(k);
+                        }
+                    ShardPlan one = plan;   // fan-out of the missing keys to this device only
+                    one.key_devices = {up_dev, d};
+                    auto table = fan_out_keys(one, src_d, bytes_d, ops);
+                    LSA_HIP(hipSetDevice(d));
+                    LSA_HIP(hipStreamSynchronize(streams.at(LanePools::key(d, ops.lane0(d)))));
+                    Avail av = avail;
+                    for (size_t k = 0; k < key_idx.size(); k++)
+                        if (cached[i * key_idx.size() + k]) av[key_idx[k]] = key_cache.at({d, key_idx[k]}).key;
+                    for (size_t j = 0; j < which.size(); j++) {
+                        const size_t k = which[j];
+                        auto dk = std::make_shared<DevKey>();
+                        dk->slab = ops.slabs.at(table.at(d)[j]);
+                        dk->key = key_src[k]->key;
+                        dk->key.data = (u64*)table.at(d)[j];
+                        dk->key.owned = false;
+                        av[key_idx[k]] = dk;
+                        if (keep_keys) {
+                            auto up = key_cache.find({up_dev, key_idx[k]});
+                            if (up != key_cache.end() && up->second.key == key_src[k])
+                                key_cache[{d, key_idx[k]}] = CachedKey{up->second.handle, up->second.fingerprint, dk};
+                        }
+                    }
+                    dev_avail[d] = std::move(av);
+                }
+                last_key_peer_copies = ops.copies;
+                LSA_HIP(hipSetDevice(up_dev));
+            }
+
             struct InFlight {
                 int chunk = -1, lane = 0;
                 size_t resume_level = 0;
                 StoreJob job;
                 std::vector<std::shared_ptr<Slab>> keep;
             };
-            // finish(): wait for the chunk's stream, wrap the results into C structs, run the import executors.  It runs on
-            // its own thread while the main thread stages and enqueues the next chunk, and touches no shared container: the
-            // structs live in a local map (only the import nodes read them), the per-lane temporaries are released by this
-            // thread while the main thread is, by construction, busy with the OTHER lane, and the progress counter has its
-            // own lock.
-            std::mutex progress_mu;
-            auto progress_locked = [&](size_t nodes_done) {
-                std::lock_guard<std::mutex> lk(progress_mu);
-                progress(nodes_done);
-            };
-            auto finish = [&](InFlight* f) {
-                const int lane = f->lane;
-                Context& lc = lane ? c1 : c;
-                hipStream_t ls = lane ? s1 : s;
-                lc.use_device();
-                auto t0 = tick();
-                LSA_HIP(hipStreamSynchronize(ls));
-                const double t_wait = ms_since(t0);
-                pending_free_.at(LanePools::key(device, lane)).clear();
-                f->keep.clear();
-                auto& cl = chunk_levels[f->chunk];
-                t0 = tick();
-                std::unordered_map<NodeIndex, std::any> local;
-                stores_finish(lc, f->job, local);
-                f->job = StoreJob{};
-                progress_locked(cl[f->resume_level].size());
-                for (size_t l = f->resume_level + 1; l < cl.size(); l++) {
-                    if (cl[l].empty()) continue;
-                    Split sp = split(cl[l]);
-                    LSA_REQUIRE(sp.loads.empty() && sp.stores.empty() && sp.bucket_order.empty(), "pipeline plan violated");
-                    run_cpu_nodes(sp.cpu, local, out_handles);
-                    progress_locked(cl[l].size());
-                }
-                if (trace) fprintf(stderr, "[lsa task] chunk %d lane %d: waited %.2f ms, import %.2f ms\n", f->chunk, lane, t_wait, ms_since(t0));
-                f->chunk = -1;
-            };
-            InFlight fly[2];
-            std::future<void> done[2];
-            auto join = [&](int lane) {
-                if (done[lane].valid()) done[lane].get();   // rethrows what the finisher threw
-            };
-            try {
-                for (size_t ch = 0; ch < chunk_levels.size(); ch++) {
-                    const int lane = (int)(ch & 1);
-                    join(lane);                   // the lane's previous chunk (two chunks in flight at most)
-                    cur_lane = lane;
-                    Context& lc = lane ? c1 : c;
-                    hipStream_t ls = lane ? s1 : s;
+            // One shard: its chunks in order, alternating its two lanes (stream + context + device-buffer pool each).  While
+            // one lane's chunk computes and copies its results out, the other lane's chunk is staged and copied in.
+            auto run_shard = [&](int si) {
+                const ShardPlan::Shard sh = plan.shards[(size_t)si];
+                tls_exec.device = sh.device;
+                tls_exec.lane = sh.lane0;
+                Context* lane_ctx[2] = {&context(sh.device, sh.lane0), &context(sh.device, sh.lane0 + 1)};
+                hipStream_t lane_stream[2] = {streams.at(LanePools::key(sh.device, sh.lane0)), streams.at(LanePools::key(sh.device, sh.lane0 + 1))};
+                Avail my_avail = dev_avail.at(sh.device);   // the shard's own view: its chunks' data + the device's keys
+                Refs my_refs = refs;
+                // finish(): wait for the chunk's stream, wrap the results into C structs, run the import executors.  It runs on
+                // its own thread while the shard's thread stages and enqueues the next chunk, and touches no shared container:
+                // the structs live in a local map (only the import nodes read them), the per-lane temporaries are released by
+                // this thread while the shard's thread is, by construction, busy with the OTHER lane.
+                auto finish = [&](InFlight* f) {
+                    const int li = f->lane;
+                    Context& lc = *lane_ctx[li];
+                    hipStream_t ls = lane_stream[li];
                     lc.use_device();
-                    InFlight& f = fly[lane];
-                    f.chunk = (int)ch;
-                    f.lane = lane;
-                    auto& cl = chunk_levels[ch];
                     auto t0 = tick();
-                    for (size_t l = 0; l < cl.size(); l++) {
+                    LSA_HIP(hipStreamSynchronize(ls));
+                    const double t_wait = ms_since(t0);
+                    pending_free_.at(LanePools::key(sh.device, sh.lane0 + li)).clear();
+                    f->keep.clear();
+                    auto& cl = chunk_levels[f->chunk];
+                    t0 = tick();
+                    Avail local;
+                    stores_finish(lc, f->job, local);
+                    f->job = StoreJob{};
+                    progress(cl[f->resume_level].size());
+                    for (size_t l = f->resume_level + 1; l < cl.size(); l++) {
                         if (cl[l].empty()) continue;
                         Split sp = split(cl[l]);
-                        if (!sp.stores.empty()) {     // copy-out enqueued; the rest of the chunk happens in finish()
-                            f.job = stores_enqueue(lc, ls, sp.stores, avail);   // holds the device data alive until the copy ran
-                            f.resume_level = l;
-                            release_inputs(cl[l]);
-                            for (size_t l2 = l + 1; l2 < cl.size(); l2++) release_inputs(cl[l2]);
-                            break;
-                        }
-                        if (!sp.cpu.empty()) run_cpu_nodes(sp.cpu, avail, out_handles);   // export executors
-                        if (!sp.loads.empty()) f.keep.push_back(run_loads(lc, ls, sp.loads, avail));
-                        run_buckets(lc, ls, sp.buckets, sp.bucket_order, avail);
-                        release_inputs(cl[l]);
-                        progress_locked(cl[l].size());
+                        LSA_REQUIRE(sp.loads.empty() && sp.stores.empty() && sp.bucket_order.empty(), "pipeline plan violated");
+                        run_cpu_nodes(sp.cpu, local, out_handles);
+                        progress(cl[l].size());
                     }
-                    if (trace) fprintf(stderr, "[lsa task] chunk %zu lane %d: enqueued in %.2f ms\n", ch, lane, ms_since(t0));
-                    done[lane] = std::async(std::launch::async, finish, &f);
+                    if (trace) fprintf(stderr, "[lsa task] chunk %d device %d lane %d: waited %.2f ms, import %.2f ms\n", f->chunk, sh.device, sh.lane0 + li, t_wait, ms_since(t0));
+                    f->chunk = -1;
+                };
+                InFlight fly[2];
+                std::future<void> done[2];
+                auto join = [&](int li) {
+                    if (done[li].valid()) done[li].get();   // rethrows what the finisher threw
+                };
+                try {
+                    int mine = 0;
+                    for (size_t ch = 0; ch < chunk_levels.size(); ch++) {
+                        if (plan.chunk_shard[ch] != si) continue;
+                        const int li = mine++ & 1;
+                        join(li);                   // the lane's previous chunk (two chunks in flight at most per shard)
+                        tls_exec.lane = sh.lane0 + li;
+                        Context& lc = *lane_ctx[li];
+                        hipStream_t ls = lane_stream[li];
+                        lc.use_device();
+                        InFlight& f = fly[li];
+                        f.chunk = (int)ch;
+                        f.lane = li;
+                        auto& cl = chunk_levels[ch];
+                        auto t0 = tick();
+                        for (size_t l = 0; l < cl.size(); l++) {
+                            if (cl[l].empty()) continue;
+                            Split sp = split(cl[l]);
+                            if (!sp.stores.empty()) {     // copy-out enqueued; the rest of the chunk happens in finish()
+                                f.job = stores_enqueue(lc, ls, sp.stores, my_avail);   // holds the device data alive until the copy ran
+                                f.resume_level = l;
+                                release_inputs(cl[l], my_avail, my_refs);
+                                for (size_t l2 = l + 1; l2 < cl.size(); l2++) release_inputs(cl[l2], my_avail, my_refs);
+                                break;
+                            }
+                            if (!sp.cpu.empty()) run_cpu_nodes(sp.cpu, my_avail, out_handles);   // export executors
+                            if (!sp.loads.empty()) f.keep.push_back(run_loads(lc, ls, sp.loads, my_avail));
+                            run_buckets(lc, ls, sp.buckets, sp.bucket_order, my_avail);
+                            release_inputs(cl[l], my_avail, my_refs);
+                            progress(cl[l].size());
+                        }
+                        if (trace) fprintf(stderr, "[lsa task] chunk %zu device %d lane %d: enqueued in %.2f ms\n", ch, sh.device, sh.lane0 + li, ms_since(t0));
+                        done[li] = std::async(std::launch::async, finish, &f);
+                    }
+                    join(0);
+                    join(1);
+                } catch (...) {
+                    for (int li = 0; li < 2; li++)     // never leave a finisher running on our stack frame
+                        if (done[li].valid()) {
+                            try {
+                                done[li].get();
+                            } catch (...) {
+                            }
+                        }
+                    throw;
                 }
-                join(0);
-                join(1);
-            } catch (...) {
-                for (int lane = 0; lane < 2; lane++)     // never leave a finisher running on our stack frame
-                    if (done[lane].valid()) {
+            };
+            if (plan.shards.size() == 1) {
+                run_shard(0);
+            } else {
+                // one host thread per shard; the first failure is reported once every shard has stopped
+                std::vector<std::exception_ptr> errs(plan.shards.size());
+                std::vector<std::thread> workers;
+                for (size_t si = 0; si < plan.shards.size(); si++)
+                    workers.emplace_back([&, si]() {
                         try {
-                            done[lane].get();
+                            run_shard((int)si);
                         } catch (...) {
+                            errs[si] = std::current_exception();
                         }
+                    });
+                for (auto& w : workers) w.join();
+                for (auto& e : errs)
+                    if (e) {
+                        tls_exec.device = up_dev;
+                        tls_exec.lane = 0;
+                        std::rethrow_exception(e);
                     }
-                cur_lane = 0;
-                throw;
             }
-            cur_lane = 0;
+            tls_exec.device = up_dev;
+            tls_exec.lane = 0;
+            c.use_device();
         }
         LSA_HIP(hipStreamSynchronize(s));
         last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
@@ -1541,6 +1760,45 @@ int lsa_frontend_bind(fhe_task_handle handle) {
     return task_guard([&] {
         LSA_REQUIRE(handle != nullptr, "null task");
         handle->g.bind_bridge_executors(frontend_export(), frontend_import());
+    });
+}
+
+int lsa_task_set_devices(fhe_task_handle handle, const int* device_ids, int n_devices) {
+    return task_guard([&] {
+        LSA_REQUIRE(handle != nullptr && n_devices >= 0 && (n_devices == 0 || device_ids != nullptr), "bad device list");
+        std::lock_guard<std::mutex> lk(handle->run_mu);
+        std::vector<int> ids(device_ids, device_ids + n_devices);
+        try {
+            if (!ids.empty()) (void)plan_shards(ids, 0);   // validates the list
+        } catch (const std::invalid_argument& e) {
+            throw Error(LSA_ERR_ARG, e.what());
+        }
+        handle->devices_ = ids;
+    });
+}
+
+int lsa_task_drop_keys(fhe_task_handle handle) {
+    return task_guard([&] {
+        LSA_REQUIRE(handle != nullptr, "null task");
+        std::lock_guard<std::mutex> lk(handle->run_mu);
+        handle->key_cache.clear();   // the device copies return to their pools
+    });
+}
+
+int lsa_task_last_run_keys(fhe_task_handle handle, int* uploaded, int* reused) {
+    return task_guard([&] {
+        LSA_REQUIRE(handle != nullptr, "null task");
+        if (uploaded) *uploaded = handle->last_key_uploads;
+        if (reused) *reused = handle->last_key_hits;
+    });
+}
+
+int lsa_task_last_run_shards(fhe_task_handle handle, int* n_shards, int* n_chunks, int* key_peer_copies) {
+    return task_guard([&] {
+        LSA_REQUIRE(handle != nullptr, "null task");
+        if (n_shards) *n_shards = handle->last_shards;
+        if (n_chunks) *n_chunks = handle->last_chunks;
+        if (key_peer_copies) *key_peer_copies = handle->last_key_peer_copies;
     });
 }
 

@@ -60,6 +60,14 @@ def _task_lib():
         L.lsa_frontend_bind.argtypes = [ctypes.c_void_p]
         L.lsa_task_trim_pools.restype = ctypes.c_int
         L.lsa_task_trim_pools.argtypes = [ctypes.c_void_p]
+        L.lsa_task_set_devices.restype = ctypes.c_int
+        L.lsa_task_set_devices.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        L.lsa_task_last_run_shards.restype = ctypes.c_int
+        L.lsa_task_last_run_shards.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 3
+        L.lsa_task_drop_keys.restype = ctypes.c_int
+        L.lsa_task_drop_keys.argtypes = [ctypes.c_void_p]
+        L.lsa_task_last_run_keys.restype = ctypes.c_int
+        L.lsa_task_last_run_keys.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 2
         L.lsa_task_counts.restype = ctypes.c_int
         L.lsa_task_counts.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 4
         L.lsa_task_last_run_stats.restype = ctypes.c_int
@@ -171,6 +179,33 @@ class FheTaskGpu:
         rc = L.lsa_task_trim_pools(self.h)
         if rc:
             raise LsaError(rc, L.lsa_last_error().decode())
+
+    def set_devices(self, device_ids):
+        """spread the runs of this task over these devices (an index may repeat: two logical shards on one device); [] clears
+        the list (lsa_task_set_devices, include/lattisense_task.h)"""
+        L = _task_lib()
+        ids = list(device_ids)
+        arr = (ctypes.c_int * max(len(ids), 1))(*ids)
+        rc = L.lsa_task_set_devices(self.h, arr, len(ids))
+        if rc:
+            raise LsaError(rc, L.lsa_last_error().decode())
+
+    def last_run_shards(self):
+        v = [ctypes.c_int() for _ in range(3)]
+        _task_lib().lsa_task_last_run_shards(self.h, *[ctypes.byref(x) for x in v])
+        return dict(zip(("shards", "chunks", "key_peer_copies"), [x.value for x in v]))
+
+    def drop_keys(self):
+        """frees the evaluation keys kept on the device(s) between runs (lsa_task_drop_keys); the next run uploads them again"""
+        L = _task_lib()
+        rc = L.lsa_task_drop_keys(self.h)
+        if rc:
+            raise LsaError(rc, L.lsa_last_error().decode())
+
+    def last_run_keys(self):
+        a, b = ctypes.c_int(), ctypes.c_int()
+        _task_lib().lsa_task_last_run_keys(self.h, ctypes.byref(a), ctypes.byref(b))
+        return {"uploaded": a.value, "reused": b.value}
 
     def counts(self):
         v = [ctypes.c_int() for _ in range(4)]

@@ -429,3 +429,113 @@ def test_pipelined_lanes_match_the_sequential_run(monkeypatch):
     for i in range(N_OP):
         assert np.array_equal(zs[i].data, o.bfv_mult_relin(lvl, xs[i], ys[i], rlk, lvl))
     t.close()
+
+
+def test_sharded_scheduler_matches_the_single_lane_run(monkeypatch):
+    """Multi-device execution behind run_fhe_gpu_task (lsa_task_set_devices): the independent subgraphs are dealt out
+    to (device, lane pair) shards, the keys are uploaded once.  On the one-GPU box the scheduler runs with the list [0] and with
+    [0, 0] -- two logical shards, four lanes, two host threads on one device, sharing the device's key copy -- and must give the
+    bits of the plain sequential run (LSA_NO_PIPELINE) and of the oracle.  Unmeasured on more than one physical device."""
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, GaloisKey, KeySwitchKey
+    from oracle.client import galois_element_for_col_rotation
+    g, P, o, c = _load("ckks_n4096_cmc_relin_rescale")
+    n, lvl = P["n"], 4
+    n_op = N_OP
+    _, xs = _ckks_inputs(c, n, lvl, n_op, 41)
+    _, ys = _ckks_inputs(c, n, lvl, n_op, 42)
+    rlk = c.gen_relin_key(lvl)
+
+    def run(devices, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        t = _task("ckks_n4096_cmc_relin_rescale")
+        try:
+            if devices is not None:
+                t.set_devices(devices)
+            zs = [Ciphertext.empty(1, lvl - 1, n) for _ in range(n_op)]
+            for _ in range(2):   # the second run reuses every shard's pooled buffers
+                t.run([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
+                       Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("out_z_list", zs)],
+                      gpu_device=0)
+            return [z.data.copy() for z in zs], t.last_run_shards(), t.last_run_stats()
+        finally:
+            t.close()
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+
+    seq, sh, _ = run(None, {"LSA_NO_PIPELINE": "1"})
+    assert sh["shards"] == 1 and sh["chunks"] == 0
+    one, sh1, st1 = run([0], {"LSA_PIPELINE_MIN_MIB": "0"})
+    assert sh1["shards"] == 1 and sh1["chunks"] == 2 and sh1["key_peer_copies"] == 0
+    two, sh2, st2 = run([0, 0], {"LSA_PIPELINE_MIN_MIB": "0"})
+    assert sh2["shards"] == 2 and sh2["chunks"] == 2 and sh2["key_peer_copies"] == 0   # same device: the key copy is shared
+    assert st2["gpu_nodes"] == n_op
+    for i in range(n_op):
+        want = o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk, lvl)
+        assert np.array_equal(seq[i], want) and np.array_equal(one[i], want) and np.array_equal(two[i], want)
+    # a device the box does not have is refused with an error code, the handle stays usable
+    t = _task("ckks_n4096_cmc_relin_rescale")
+    try:
+        monkeypatch.setenv("LSA_PIPELINE_MIN_MIB", "0")
+        t.set_devices([0, 97])
+        zs = [Ciphertext.empty(1, lvl - 1, n) for _ in range(n_op)]
+        args = ([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
+                 Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])], [Argument("out_z_list", zs)])
+        with pytest.raises(Exception):
+            t.run(*args)
+        t.set_devices([0, 0])
+        t.run(*args)
+        for i in range(n_op):
+            assert np.array_equal(zs[i].data, seq[i])
+        with pytest.raises(Exception):
+            t.set_devices([-3])
+    finally:
+        t.close()
+
+
+def test_keys_stay_resident_across_runs_and_a_new_key_is_noticed():
+    """run 1 uploads and converts the relinearisation key, run 2 with the same key object reuses the device copy, a regenerated
+    key written into the same object is detected by its fingerprint (and the results follow the NEW key), lsa_task_drop_keys
+    forces an upload (include/lattisense_task.h; the reference uploads every key on every run, cxx_argument.h:178-260)"""
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, KeySwitchKey
+    g, P, o, c = _load("ckks_n4096_cmc_relin_rescale")
+    n, lvl = P["n"], 4
+    _, xs = _ckks_inputs(c, n, lvl, N_OP, 51)
+    _, ys = _ckks_inputs(c, n, lvl, N_OP, 52)
+    rlk = c.gen_relin_key(lvl)
+    key_obj = KeySwitchKey(rlk.copy(), lvl, len(P["p"]))
+    t = _task("ckks_n4096_cmc_relin_rescale")
+    zs = [Ciphertext.empty(1, lvl - 1, n) for _ in range(N_OP)]
+    args = ([Argument("in_x_list", [Ciphertext(x) for x in xs]), Argument("in_y_list", [Ciphertext(y) for y in ys]),
+             Argument("rlk_ntt", [key_obj])], [Argument("out_z_list", zs)])
+    try:
+        t.run(*args)
+        assert t.last_run_keys() == {"uploaded": 1, "reused": 0}
+        t.run(*args)
+        assert t.last_run_keys() == {"uploaded": 0, "reused": 1}
+        for i in range(N_OP):
+            assert np.array_equal(zs[i].data, o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk, lvl))
+        # a different key behind the same handle
+        from oracle.client import Client
+        rlk2 = Client(o, seed=991).gen_relin_key(lvl)
+        assert not np.array_equal(rlk2, rlk)
+        key_obj.data[...] = rlk2
+        t.run(*args)
+        assert t.last_run_keys() == {"uploaded": 1, "reused": 0}
+        for i in range(N_OP):
+            assert np.array_equal(zs[i].data, o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk2, lvl))
+        t.run(*args)
+        assert t.last_run_keys()["reused"] == 1
+        t.drop_keys()
+        t.run(*args)
+        assert t.last_run_keys() == {"uploaded": 1, "reused": 0}
+        # another key OBJECT with the first key's contents: not the cached handle -> uploaded
+        args2 = (args[0][:2] + [Argument("rlk_ntt", [KeySwitchKey(rlk.copy(), lvl, len(P["p"]))])], args[1])
+        t.run(*args2)
+        assert t.last_run_keys()["uploaded"] == 1
+        for i in range(N_OP):
+            assert np.array_equal(zs[i].data, o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk, lvl))
+    finally:
+        t.close()
