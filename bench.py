@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--dual-stream", action="store_true", help="overlap alternate tiles on an auxiliary stream (A/B)")
     ap.add_argument("--no-fuse", action="store_true", help="separate ModDown/rescale tail kernels (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pinned-alloc", action="store_true", help="task workloads: caller buffers from lsa_host_alloc, copied without staging (A/B: slower on the measured hosts)")
+    ap.add_argument("--register-in-place", action="store_true", help="task workloads: caller buffers pinned in place with lsa_host_register (A/B)")
     ap.add_argument("--prof-stride", type=int, default=4)
     ap.add_argument("--log-slots", type=int, default=0, help="bootstrap workload: log2 of the packed slots (0 = dense, N/2)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
@@ -234,6 +236,26 @@ def run_task_workload(args):
     t = FheTaskGpu(path)
     ins = [Argument("xs", xs), Argument("ys", ys), Argument("rlk_ntt", [rlk])]
     outs = [Argument("zs", zs)]
+    pinned = []
+    if args.register_in_place:   # A/B: the caller's own buffers pinned in place (lsa_host_register)
+        from lattisense_amd.task import register_host
+        for obj in xs + ys + zs:
+            register_host(obj.data)
+            pinned.append(obj.data)
+    elif args.pinned_alloc:   # the caller keeps its limbs in pinned memory from the library's allocator: zero-copy ingestion
+        from lattisense_amd.task import alloc_host
+
+        def to_pinned(cts):
+            out = []
+            for ct in cts:
+                a = alloc_host(ct.data.shape)
+                a[...] = ct.data
+                pinned.append(a)
+                out.append(Ciphertext(a))
+            return out
+        xs, ys, zs = to_pinned(xs), to_pinned(ys), to_pinned(zs)
+        ins = [Argument("xs", xs), Argument("ys", ys), Argument("rlk_ntt", [rlk])]
+        outs = [Argument("zs", zs)]
     for _ in range(args.warmup):
         t.run(ins, outs)
     t0 = time.perf_counter()
@@ -247,7 +269,8 @@ def run_task_workload(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": name + " through run_fhe_gpu_task (host buffers, PCIe-inclusive)", "n_op": n_op,
                    "gpu_nodes": st["gpu_nodes"], "batched_launch_groups": st["gpu_batches"],
-                   "keys_last_run": t.last_run_keys()},
+                   "keys_last_run": t.last_run_keys(), "direct_copies_last_run": t.last_run_direct(),
+                   "caller_buffers": "pinned in place" if args.register_in_place else ("library pinned allocator" if args.pinned_alloc else "pageable (staged)")},
         "roofline": None, "cpu_baseline": None}), flush=True)
 
 

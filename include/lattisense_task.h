@@ -19,6 +19,7 @@
  */
 #ifndef LATTISENSE_TASK_H
 #define LATTISENSE_TASK_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -137,6 +138,18 @@ int lsa_task_trim_pools(fhe_task_handle handle);
  * gpu_device = -1: every visible device) the gpu_device argument of run_fhe_gpu_task is ignored. */
 int lsa_task_set_devices(fhe_task_handle handle, const int* device_ids, int n_devices);
 int lsa_task_last_run_shards(fhe_task_handle handle, int* n_shards, int* n_chunks, int* key_peer_copies);
+
+/* Zero-copy ingestion for callers of the native front-end: limb buffers inside a range registered here (pinned in
+ * place) are DMA'd from / into directly -- an input ciphertext or plaintext whose limbs are one contiguous block is copied to
+ * the device from where it lies, a result is copied straight into the pre-allocated output ciphertext -- instead of going
+ * through the pinned staging slabs.  The caller owns the lifetime: keep the range allocated until lsa_host_unregister.
+ * Everything else (foreign executors' per-limb structs, unregistered buffers) takes the staged path. */
+int lsa_host_register(void* ptr, size_t bytes);
+int lsa_host_unregister(void* ptr);
+/* pinned memory allocated for the caller (the fast path: full PCIe rate; pin-in-place registration measured slower than staging) */
+int lsa_host_alloc(size_t bytes, void** out);
+int lsa_host_free(void* ptr);
+int lsa_task_last_run_direct(fhe_task_handle handle, int* loads, int* stores);
 
 /* Evaluation keys stay resident on the device(s) across run() calls: a run whose export executor yields the same caller
  * handle and the same fingerprint (shape + three sampled words of every limb of the exported C struct) for a key datum reuses

@@ -79,6 +79,29 @@ void lsa_free_ciphertext(CCiphertext* ct) {
 
 namespace {
 
+// ------------------------------------------------------------------------------------------------ caller-pinned host memory
+// Zero-copy ingestion: a caller that keeps its limb buffers in memory it has registered with lsa_host_register
+// (pinned in place, hipHostRegister) gets its ciphertexts DMA'd straight from / into those buffers -- no gather into a staging
+// slab on the way in, no copy out of one on the way back.  The caller owns the lifetime: the range must stay allocated until
+// lsa_host_unregister.  Unregistered buffers take the pinned-staging path as before.
+struct HostRegistry {
+    std::mutex mu;
+    std::map<uintptr_t, size_t> ranges;   // base -> bytes
+    bool covers(const void* p, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (ranges.empty()) return false;
+        const uintptr_t a = (uintptr_t)p;
+        auto it = ranges.upper_bound(a);
+        if (it == ranges.begin()) return false;
+        --it;
+        return a >= it->first && a + bytes <= it->first + it->second;
+    }
+};
+HostRegistry& host_registry() {
+    static HostRegistry r;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------ device data
 // Buffers (device or pinned host) recycled across levels and run() calls: hipMalloc/hipFree and pinned allocation cost
 // milliseconds and synchronise the device, so a task keeps what it allocated (buf_pool.h: best fit, a cap on what stays
@@ -532,12 +555,35 @@ struct fhe_task_handle_st {
                 key_nodes.push_back(node);
             }
         }
+        // a group whose every item is one contiguous block of caller-registered (pinned) memory is copied from where it lies
+        auto item_base = [&](const Item& it) -> const u64* {
+            const u64* base = (it.ct ? it.ct->polys[0] : it.pt->poly).components[0].data;
+            const u64* want = base;
+            for (int p = 0; p < it.polys; p++) {
+                const CPolynomial& poly = it.ct ? it.ct->polys[p] : it.pt->poly;
+                for (int j = 0; j <= it.level; j++, want += N)
+                    if (poly.components[j].data != want) return nullptr;
+            }
+            return host_registry().covers(base, (size_t)it.polys * (it.level + 1) * N * sizeof(u64)) ? base : nullptr;
+        };
+        std::map<std::tuple<int, int, int>, std::vector<const u64*>> direct;   // group -> per-item host base (all or nothing)
+        for (auto& kv : groups) {
+            std::vector<const u64*> bases;
+            for (auto& it : kv.second) {
+                const u64* b = item_base(it);
+                if (!b) break;
+                bases.push_back(b);
+            }
+            if (bases.size() == kv.second.size()) direct[kv.first] = std::move(bases);
+        }
         size_t total = 0;
-        for (auto& kv : groups)
+        for (auto& kv : groups) {
+            if (direct.count(kv.first)) continue;
             for (auto& it : kv.second) {
                 it.off = total;
                 total += (size_t)it.polys * (it.level + 1) * N;
             }
+        }
         // keys: compact order [beta][2][comp][N]
         struct KeyItem {
             ComputeNode* node;
@@ -602,6 +648,23 @@ struct fhe_task_handle_st {
             total += (size_t)k.beta * 2 * k.comp * N;
             keys.push_back(std::move(k));
         }
+        // 1b. direct groups: device slab + one copy per item straight from the caller's pinned buffer
+        for (auto& kv : direct) {
+            auto& items = groups.at(kv.first);
+            const size_t per = (size_t)items[0].polys * (items[0].level + 1) * N;
+            auto slab = dslab(per * items.size());
+            for (size_t i = 0; i < items.size(); i++) {
+                LSA_HIP(hipMemcpyAsync(slab->ptr + per * i, kv.second[i], per * sizeof(u64), hipMemcpyHostToDevice, s));
+                auto d = std::make_shared<DevDatum>();
+                d->slab = slab;
+                d->ptr = slab->ptr + per * i;
+                d->polys = items[i].polys;
+                d->level = items[i].level;
+                d->is_plain = std::get<0>(kv.first) == 1;
+                avail[items[i].node->output_nodes[0]->index] = d;
+            }
+            last_direct_loads += (int)items.size();
+        }
         if (total == 0) return nullptr;
         // 2. gather limbs into a pinned staging slab, one H2D copy per group
         auto hstage = pslab(total);
@@ -611,7 +674,8 @@ struct fhe_task_handle_st {
             const u64* src;
         };
         std::vector<Job> jobs;   // one limb each, gathered by a few threads (single-threaded this was ~55 % of LOAD)
-        for (auto& kv : groups)
+        for (auto& kv : groups) {
+            if (direct.count(kv.first)) continue;
             for (auto& it : kv.second) {
                 u64* dst = host + it.off;
                 for (int p = 0; p < it.polys; p++) {
@@ -622,6 +686,7 @@ struct fhe_task_handle_st {
                     }
                 }
             }
+        }
         for (auto& k : keys) {
             u64* dst = host + k.off;
             for (int d = 0; d < k.beta; d++)
@@ -638,6 +703,7 @@ struct fhe_task_handle_st {
         };
         std::vector<Seg> segs;
         for (auto& kv : groups) {
+            if (direct.count(kv.first)) continue;
             auto& items = kv.second;
             const size_t per = (size_t)items[0].polys * (items[0].level + 1) * N;
             auto slab = dslab(per * items.size());
@@ -693,42 +759,69 @@ struct fhe_task_handle_st {
     // ---------------------------------------------------------------- STORE_FROM_BACKEND (batched D2H)
     struct StoreJob {
         std::vector<ComputeNode*> nodes;
-        std::vector<std::pair<DatumP, size_t>> items;
+        std::vector<std::pair<DatumP, size_t>> items;   // offset into the pinned slab (staged results)
+        std::vector<u64*> direct;                       // non-null: the result was copied straight into the caller's buffer
         std::shared_ptr<Slab> hslab;
     };
+    bool native_frontend = false;                                  // lsa_frontend_bind: output handles are lsa_host_ciphertext
+    const std::unordered_map<NodeIndex, void*>* run_out_handles = nullptr;   // the current run's output handles (read-only)
+    std::atomic<int> last_direct_loads{0}, last_direct_stores{0};
     void run_stores(Context& c, hipStream_t s, const std::vector<ComputeNode*>& nodes,
                     std::unordered_map<NodeIndex, std::any>& avail) {
         StoreJob j = stores_enqueue(c, s, nodes, avail);
         LSA_HIP(hipStreamSynchronize(s));
         stores_finish(c, j, avail);
     }
+    // where a store node's result can be written directly: the native front-end's pre-allocated output ciphertext behind the
+    // import node that follows, if the caller registered (pinned) its buffer and it has the result's shape
+    u64* direct_store_target(const ComputeNode* store, const DevDatum& d, int n) {
+        if (!native_frontend || !run_out_handles) return nullptr;
+        const DatumNode* cs = store->output_nodes[0];
+        if (cs->successors.size() != 1 || cs->successors[0]->op() != OperationType::IMPORT_FROM_ABI) return nullptr;
+        auto it = run_out_handles->find(cs->successors[0]->output_nodes[0]->index);
+        if (it == run_out_handles->end() || !it->second) return nullptr;
+        const auto* h = (const lsa_host_ciphertext*)it->second;
+        if (!h->data || h->n != n || h->level != d.level || h->degree != d.polys - 1) return nullptr;
+        const size_t bytes = (size_t)d.polys * (d.level + 1) * n * sizeof(u64);
+        return host_registry().covers(h->data, bytes) ? h->data : nullptr;
+    }
     StoreJob stores_enqueue(Context& c, hipStream_t s, const std::vector<ComputeNode*>& nodes,
                             std::unordered_map<NodeIndex, std::any>& avail) {
         const long long N = c.n;
         size_t total = 0;
         std::vector<std::pair<DatumP, size_t>> items;
+        std::vector<u64*> direct;
         for (ComputeNode* node : nodes) {
             const DatumNode* in = node->input_nodes[0];
             LSA_REQUIRE(in->datum_type == TYPE_CIPHERTEXT, "Unsupported data type for D2H transfer");
             auto d = std::any_cast<DatumP>(avail.at(in->index));
+            u64* tgt = direct_store_target(node, *d, c.n);
+            direct.push_back(tgt);
             items.push_back({d, total});
-            total += (size_t)d->polys * (d->level + 1) * N;
+            if (!tgt) total += (size_t)d->polys * (d->level + 1) * N;
         }
-        // results land in ONE pooled pinned slab; the C structs handed to the caller's import executor only index it
+        // staged results land in ONE pooled pinned slab; the C structs handed to the caller's import executor only index it
         // (no malloc per limb, no second host copy).  The slab returns to the pool when the last struct is released.
-        auto hslab = pslab(total);
-        u64* host = hslab->ptr;
+        std::shared_ptr<Slab> hslab = total ? pslab(total) : nullptr;
+        u64* host = hslab ? hslab->ptr : nullptr;
         // merge runs that are contiguous on the device into single copies
         for (size_t i = 0; i < items.size();) {
+            if (direct[i]) {
+                const size_t words = (size_t)items[i].first->polys * (items[i].first->level + 1) * N;
+                LSA_HIP(hipMemcpyAsync(direct[i], items[i].first->ptr, words * sizeof(u64), hipMemcpyDeviceToHost, s));
+                last_direct_stores++;
+                i++;
+                continue;
+            }
             size_t j = i, words = 0;
-            while (j < items.size() && items[j].first->ptr == items[i].first->ptr + words) {
+            while (j < items.size() && !direct[j] && items[j].first->ptr == items[i].first->ptr + words) {
                 words += (size_t)items[j].first->polys * (items[j].first->level + 1) * N;
                 j++;
             }
             LSA_HIP(hipMemcpyAsync(host + items[i].second, items[i].first->ptr, words * sizeof(u64), hipMemcpyDeviceToHost, s));
             i = j;
         }
-        return StoreJob{nodes, std::move(items), hslab};
+        return StoreJob{nodes, std::move(items), std::move(direct), hslab};
     }
     // after the stream has been synchronised: wrap the pinned result slab into C structs for the import executor
     void stores_finish(Context& c, StoreJob& job, std::unordered_map<NodeIndex, std::any>& avail) {
@@ -736,14 +829,14 @@ struct fhe_task_handle_st {
         const auto& nodes = job.nodes;
         const auto& items = job.items;
         auto hslab = job.hslab;
-        u64* host = hslab->ptr;
+        u64* host = hslab ? hslab->ptr : nullptr;
         for (size_t i = 0; i < nodes.size(); i++) {
             const DatumP& d = items[i].first;
             auto* ct = (CCiphertext*)malloc(sizeof(CCiphertext));
             ct->level = d->level;
             ct->degree = d->polys - 1;
             ct->polys = (CPolynomial*)malloc(sizeof(CPolynomial) * (size_t)d->polys);
-            u64* src = host + items[i].second;
+            u64* src = job.direct[i] ? job.direct[i] : host + items[i].second;   // (direct: the struct indexes the caller's own buffer)
             for (int p = 0; p < d->polys; p++) {
                 ct->polys[p].n_component = d->level + 1;
                 ct->polys[p].components = (CComponent*)malloc(sizeof(CComponent) * (size_t)(d->level + 1));
@@ -1207,6 +1300,13 @@ struct fhe_task_handle_st {
             }
         }
         LSA_REQUIRE(oi == g.outputs.size(), "fewer output handles than task outputs");
+        run_out_handles = &out_handles;
+        struct ClearOut {
+            fhe_task_handle_st* h;
+            ~ClearOut() { h->run_out_handles = nullptr; }
+        } clear_out{this};
+        last_direct_loads = 0;
+        last_direct_stores = 0;
 
         // remaining-consumer counts: device data is dropped as soon as its last consumer has been enqueued
         std::unordered_map<NodeIndex, int> refs;
@@ -1691,8 +1791,11 @@ ExecutorFunc frontend_import() {
                                      std::to_string(dst->level) + "/" + std::to_string(dst->degree) + ", result has " +
                                      std::to_string(ct->level) + "/" + std::to_string(ct->degree));
         for (int p = 0; p <= ct->degree; p++)
-            for (int j = 0; j <= ct->level; j++)
-                memcpy(dst->data + ((size_t)p * (ct->level + 1) + j) * n, ct->polys[p].components[j].data, sizeof(uint64_t) * (size_t)n);
+            for (int j = 0; j <= ct->level; j++) {
+                uint64_t* to = dst->data + ((size_t)p * (ct->level + 1) + j) * n;
+                if (to != ct->polys[p].components[j].data)   // (equal: the backend wrote the result straight into this handle's pinned buffer)
+                    memcpy(to, ct->polys[p].components[j].data, sizeof(uint64_t) * (size_t)n);
+            }
         output = owned ? owned : std::shared_ptr<void>(dst, [](void*) {});
     };
 }
@@ -1736,6 +1839,7 @@ void bind_gpu_task_abi_bridge_executors(fhe_task_handle handle, void* abi_export
         // copied by value, the caller may free its std::function objects afterwards (gpu_wrapper.cu:492-497)
         handle->g.bind_bridge_executors(*reinterpret_cast<ExecutorFunc*>(abi_export_executor),
                                         *reinterpret_cast<ExecutorFunc*>(abi_import_executor));
+        handle->native_frontend = false;   // output handles are the caller's own objects: never interpreted here
     });
 }
 
@@ -1760,6 +1864,7 @@ int lsa_frontend_bind(fhe_task_handle handle) {
     return task_guard([&] {
         LSA_REQUIRE(handle != nullptr, "null task");
         handle->g.bind_bridge_executors(frontend_export(), frontend_import());
+        handle->native_frontend = true;
     });
 }
 
@@ -1774,6 +1879,56 @@ int lsa_task_set_devices(fhe_task_handle handle, const int* device_ids, int n_de
             throw Error(LSA_ERR_ARG, e.what());
         }
         handle->devices_ = ids;
+    });
+}
+
+int lsa_host_register(void* ptr, size_t bytes) {
+    return task_guard([&] {
+        LSA_REQUIRE(ptr != nullptr && bytes > 0, "null range");
+        LSA_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+        std::lock_guard<std::mutex> lk(host_registry().mu);
+        host_registry().ranges[(uintptr_t)ptr] = bytes;
+    });
+}
+
+int lsa_host_unregister(void* ptr) {
+    return task_guard([&] {
+        {
+            std::lock_guard<std::mutex> lk(host_registry().mu);
+            LSA_REQUIRE(host_registry().ranges.erase((uintptr_t)ptr) == 1, "range was not registered");
+        }
+        LSA_HIP(hipHostUnregister(ptr));
+    });
+}
+
+// pinned memory allocated FOR the caller (hipHostMalloc: the DMA engines reach it at full PCIe rate; memory pinned in place
+// with lsa_host_register measured slower than the staged path on MI355X hosts, profiles/r03/t2_zero_copy_ab.log)
+int lsa_host_alloc(size_t bytes, void** out) {
+    return task_guard([&] {
+        LSA_REQUIRE(out != nullptr && bytes > 0, "null argument");
+        void* p = nullptr;
+        LSA_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        std::lock_guard<std::mutex> lk(host_registry().mu);
+        host_registry().ranges[(uintptr_t)p] = bytes;
+        *out = p;
+    });
+}
+
+int lsa_host_free(void* ptr) {
+    return task_guard([&] {
+        {
+            std::lock_guard<std::mutex> lk(host_registry().mu);
+            LSA_REQUIRE(host_registry().ranges.erase((uintptr_t)ptr) == 1, "not an lsa_host_alloc block");
+        }
+        LSA_HIP(hipHostFree(ptr));
+    });
+}
+
+int lsa_task_last_run_direct(fhe_task_handle handle, int* loads, int* stores) {
+    return task_guard([&] {
+        LSA_REQUIRE(handle != nullptr, "null task");
+        if (loads) *loads = handle->last_direct_loads;
+        if (stores) *stores = handle->last_direct_stores;
     });
 }
 

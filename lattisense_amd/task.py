@@ -64,6 +64,16 @@ def _task_lib():
         L.lsa_task_set_devices.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
         L.lsa_task_last_run_shards.restype = ctypes.c_int
         L.lsa_task_last_run_shards.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 3
+        L.lsa_host_register.restype = ctypes.c_int
+        L.lsa_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.lsa_host_alloc.restype = ctypes.c_int
+        L.lsa_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        L.lsa_host_free.restype = ctypes.c_int
+        L.lsa_host_free.argtypes = [ctypes.c_void_p]
+        L.lsa_host_unregister.restype = ctypes.c_int
+        L.lsa_host_unregister.argtypes = [ctypes.c_void_p]
+        L.lsa_task_last_run_direct.restype = ctypes.c_int
+        L.lsa_task_last_run_direct.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 2
         L.lsa_task_drop_keys.restype = ctypes.c_int
         L.lsa_task_drop_keys.argtypes = [ctypes.c_void_p]
         L.lsa_task_last_run_keys.restype = ctypes.c_int
@@ -75,6 +85,43 @@ def _task_lib():
                                               ctypes.POINTER(ctypes.c_double)]
         _task_sigs_done = True
     return L
+
+
+def register_host(array):
+    """pins a NumPy array's buffer in place (lsa_host_register): ciphertexts / plaintexts whose limbs lie inside it are copied
+    to and from the device without staging.  Keep the array alive until unregister_host(array)."""
+    L = _task_lib()
+    rc = L.lsa_host_register(ctypes.c_void_p(array.ctypes.data), array.nbytes)
+    if rc:
+        raise LsaError(rc, L.lsa_last_error().decode())
+
+
+def alloc_host(shape):
+    """a uint64 NumPy array in pinned memory allocated by the library (lsa_host_alloc): ciphertexts built on it are copied to and
+    from the device without staging, at full PCIe rate.  Release with free_host(array) once nothing uses it."""
+    L = _task_lib()
+    n = int(np.prod(shape))
+    p = ctypes.c_void_p()
+    rc = L.lsa_host_alloc(n * 8, ctypes.byref(p))
+    if rc:
+        raise LsaError(rc, L.lsa_last_error().decode())
+    buf = (ctypes.c_uint64 * n).from_address(p.value)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(shape)
+    return a
+
+
+def free_host(array):
+    L = _task_lib()
+    rc = L.lsa_host_free(ctypes.c_void_p(array.ctypes.data))
+    if rc:
+        raise LsaError(rc, L.lsa_last_error().decode())
+
+
+def unregister_host(array):
+    L = _task_lib()
+    rc = L.lsa_host_unregister(ctypes.c_void_p(array.ctypes.data))
+    if rc:
+        raise LsaError(rc, L.lsa_last_error().decode())
 
 
 class Ciphertext:
@@ -201,6 +248,11 @@ class FheTaskGpu:
         rc = L.lsa_task_drop_keys(self.h)
         if rc:
             raise LsaError(rc, L.lsa_last_error().decode())
+
+    def last_run_direct(self):
+        a, b = ctypes.c_int(), ctypes.c_int()
+        _task_lib().lsa_task_last_run_direct(self.h, ctypes.byref(a), ctypes.byref(b))
+        return {"loads": a.value, "stores": b.value}
 
     def last_run_keys(self):
         a, b = ctypes.c_int(), ctypes.c_int()

@@ -539,3 +539,69 @@ def test_keys_stay_resident_across_runs_and_a_new_key_is_noticed():
             assert np.array_equal(zs[i].data, o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk, lvl))
     finally:
         t.close()
+
+
+def test_registered_host_buffers_are_copied_without_staging():
+    """lsa_host_register (include/lattisense_task.h): inputs whose limbs lie in caller-pinned memory are DMA'd from where they are,
+    results straight into the pre-allocated output ciphertexts; same bits as the staged path; mixed registered / unregistered
+    operands fall back per group"""
+    need_gpu()
+    from lattisense_amd.task import Argument, Ciphertext, KeySwitchKey, register_host, unregister_host
+    g, P, o, c = _load("ckks_n4096_cmc_relin_rescale")
+    n, lvl = P["n"], 4
+    _, xs = _ckks_inputs(c, n, lvl, N_OP, 61)
+    _, ys = _ckks_inputs(c, n, lvl, N_OP, 62)
+    rlk = c.gen_relin_key(lvl)
+    X = [Ciphertext(x) for x in xs]
+    Y = [Ciphertext(y) for y in ys]
+    Z = [Ciphertext.empty(1, lvl - 1, n) for _ in range(N_OP)]
+    t = _task("ckks_n4096_cmc_relin_rescale")
+    args = ([Argument("in_x_list", X), Argument("in_y_list", Y), Argument("rlk_ntt", [KeySwitchKey(rlk, lvl, len(P["p"]))])],
+            [Argument("out_z_list", Z)])
+    want = [o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], rlk, lvl) for i in range(N_OP)]
+    pinned = []
+    try:
+        t.run(*args)
+        assert t.last_run_direct() == {"loads": 0, "stores": 0}
+        for obj in X + Y + Z:
+            register_host(obj.data)
+            pinned.append(obj.data)
+        for z in Z:
+            z.data[...] = 0
+        t.run(*args)
+        assert t.last_run_direct() == {"loads": 2 * N_OP, "stores": N_OP}
+        for i in range(N_OP):
+            assert np.array_equal(Z[i].data, want[i])
+        # one unregistered operand in the group: the whole group is staged again, the outputs stay direct
+        unregister_host(X[0].data)
+        pinned.remove(X[0].data)
+        for z in Z:
+            z.data[...] = 0
+        t.run(*args)
+        assert t.last_run_direct() == {"loads": 0, "stores": N_OP}
+        for i in range(N_OP):
+            assert np.array_equal(Z[i].data, want[i])
+        # buffers from the library's pinned allocator (the fast path) behave the same
+        from lattisense_amd.task import alloc_host, free_host
+        blocks = []
+        try:
+            def pin(ct):
+                a = alloc_host(ct.data.shape)
+                a[...] = ct.data
+                blocks.append(a)
+                return Ciphertext(a)
+            X2, Y2 = [pin(x) for x in X], [pin(y) for y in Y]
+            Z2 = [pin(z) for z in Z]
+            for z in Z2:
+                z.data[...] = 0
+            t.run([Argument("in_x_list", X2), Argument("in_y_list", Y2), args[0][2]], [Argument("out_z_list", Z2)])
+            assert t.last_run_direct() == {"loads": 2 * N_OP, "stores": N_OP}
+            for i in range(N_OP):
+                assert np.array_equal(Z2[i].data, want[i])
+        finally:
+            for a in blocks:
+                free_host(a)
+    finally:
+        t.close()
+        for a in pinned:
+            unregister_host(a)
