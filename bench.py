@@ -565,7 +565,7 @@ def main():
     ntt = breakdown.get("k_ntt_pass", None)
     roofline = None
     if ntt:
-        roofline = {"kernel": "k_ntt_pass", "bound": "hbm", "achieved": ntt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+        roofline = {"kernel": "k_ntt_r16 / k_ntt_pass (limb-transform passes)", "bound": "hbm", "achieved": ntt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": ntt["achieved_GBps"] / HBM_PEAK_GBPS, "traffic": None,
                     "avg_launch_us": ntt["avg_launch_us"], "launches_per_step": ntt["launches_per_step"],
                     "sampling": "HIP event pair around one launch in %d (hash-picked), on the launch stream" % args.prof_stride}

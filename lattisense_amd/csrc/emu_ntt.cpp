@@ -30,13 +30,13 @@ static void emu_block(const NttPassArgs& a, const NttBlockCtx& bc, u64* lds) {
 }
 
 // the radix-16-squared pass (ntt_r16.h): each phase for every thread in turn, a thread's registers kept between its phases
-template <int PASS>
+template <int PASS, int MU>
 static void emu_block_r16(const NttPassArgs& a, const NttBlockCtx& bc, u64* lds) {
     std::vector<std::array<u64, 16>> regs(LSA_R16_THREADS);
     for (int phase = 0; phase < 3; phase++)
         for (int t = 0; t < LSA_R16_THREADS; t++) {
             u64(&v)[16] = *reinterpret_cast<u64(*)[16]>(regs[t].data());
-            r16_phase<PASS, 3>(a, bc, t, lds, phase, v);
+            r16_phase<PASS, 3, MU>(a, bc, t, lds, phase, v);
         }
 }
 
@@ -91,8 +91,10 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
             NttBlockCtx bc = ntt_decode_block(a, bid);
             if (bc.mod == LSA_ROW_SKIP) continue;
             if (r16 && ntt_r16_shape_ok(a, plan.npass)) {
-                if (a.lambda) emu_block_r16<0>(a, bc, lds.data());
-                else emu_block_r16<1>(a, bc, lds.data());
+                if (a.lambda && a.mu == 8) emu_block_r16<0, 8>(a, bc, lds.data());
+                else if (a.lambda) emu_block_r16<0, 7>(a, bc, lds.data());
+                else if (a.mu == 8) emu_block_r16<1, 8>(a, bc, lds.data());
+                else emu_block_r16<1, 7>(a, bc, lds.data());
             } else if (a.tau <= 12) emu_block<LSA_NTT_THREADS>(a, bc, lds.data());
             else if (a.tau == 13) emu_block<512>(a, bc, lds.data());
             else emu_block<1024>(a, bc, lds.data());

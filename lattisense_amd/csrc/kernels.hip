@@ -136,19 +136,19 @@ __device__ __forceinline__ void r16_sync() {
 #ifndef LSA_R16_WAVES
 #define LSA_R16_WAVES 4
 #endif
-template <int PASS, int FZ>
+template <int PASS, int FZ, int MU>
 __global__ __launch_bounds__(LSA_R16_THREADS, (FZ & 1) ? LSA_NTT_WAVES_FUSED : LSA_R16_WAVES) void k_ntt_r16(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const int tid = threadIdx.x;
     const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
     if (bc.mod == LSA_ROW_SKIP) return;  // uniform per block, before any barrier
     u64 v[16];
-    r16_phase<PASS, FZ>(a, bc, tid, lds, 0, v);
+    r16_phase<PASS, FZ, MU>(a, bc, tid, lds, 0, v);
     if (!(PASS == 0 && a.inverse)) r16_sync<PASS>();   // (first pass, inverse: phase 0 only filled registers)
-    r16_phase<PASS, FZ>(a, bc, tid, lds, 1, v);
+    r16_phase<PASS, FZ, MU>(a, bc, tid, lds, 1, v);
     if (PASS == 0 && !a.inverse) return;                // (first pass, forward: phase 1 stored the results)
     r16_sync<PASS>();
-    r16_phase<PASS, FZ>(a, bc, tid, lds, 2, v);
+    r16_phase<PASS, FZ, MU>(a, bc, tid, lds, 2, v);
 }
 static bool ntt_launch_r16(const NttPassArgs& a, int npass, bool fused, long long nblocks, hipStream_t s) {
     static const bool enabled = [] {
@@ -167,12 +167,22 @@ static bool ntt_launch_r16(const NttPassArgs& a, int npass, bool fused, long lon
     }();
     if (a.lambda) {
         if (epi || (pro && !pro_enabled)) return false;   // (a first pass is never the last one of a two-pass plan)
-        if (pro) hipLaunchKernelGGL((k_ntt_r16<0, 1>), grid, block, lds_bytes, s, a);
-        else hipLaunchKernelGGL((k_ntt_r16<0, 0>), grid, block, lds_bytes, s, a);
+        if (a.mu == 8) {
+            if (pro) hipLaunchKernelGGL((k_ntt_r16<0, 1, 8>), grid, block, lds_bytes, s, a);
+            else hipLaunchKernelGGL((k_ntt_r16<0, 0, 8>), grid, block, lds_bytes, s, a);
+        } else {
+            if (pro) return false;
+            hipLaunchKernelGGL((k_ntt_r16<0, 0, 7>), grid, block, lds_bytes, s, a);
+        }
     } else {
         if (pro) return false;
-        if (epi) hipLaunchKernelGGL((k_ntt_r16<1, 2>), grid, block, lds_bytes, s, a);
-        else hipLaunchKernelGGL((k_ntt_r16<1, 0>), grid, block, lds_bytes, s, a);
+        if (a.mu == 8) {
+            if (epi) hipLaunchKernelGGL((k_ntt_r16<1, 2, 8>), grid, block, lds_bytes, s, a);
+            else hipLaunchKernelGGL((k_ntt_r16<1, 0, 8>), grid, block, lds_bytes, s, a);
+        } else {
+            if (epi) hipLaunchKernelGGL((k_ntt_r16<1, 2, 7>), grid, block, lds_bytes, s, a);
+            else hipLaunchKernelGGL((k_ntt_r16<1, 0, 7>), grid, block, lds_bytes, s, a);
+        }
     }
     LSA_HIP(hipGetLastError());
     return true;

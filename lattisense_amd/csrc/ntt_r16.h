@@ -25,22 +25,30 @@
 
 // PASS 0: first pass of a two-pass plan  {s_lo = 0, mu = 8, lambda = 4, tau = 12}: local l = (i << 4) | k   (k = column)
 // PASS 1: second pass                    {s_lo = logn - 8, mu = 8, lambda = 0, tau = 12}: l = (k << 8) | i  (k = 256-point chunk)
+// MU = 8: a pass of 8 stages = two radix-16 groups per point (N = 2^16 both passes, 2^15 second, 2^17 first);
+// MU = 7: 7 stages = a radix-16 group and a radix-8 group, two of the latter per thread (N = 2^14 both passes, 2^15 first).
+// The twiddle tables are laid out for the plan's radix split (ntt_split): 4 + (MU - 4) for exactly these two.
 LSA_HD bool ntt_r16_shape_ok(const NttPassArgs& a, int npass) {
-    if (npass != 2 || a.mu != 8 || a.tau != 12) return false;
-    return (a.s_lo == 0 && a.lambda == 4) || (a.s_lo == a.logn - 8 && a.lambda == 0);
+    if (npass != 2 || (a.mu != 8 && a.mu != 7) || a.tau != 12) return false;
+    return (a.s_lo == 0 && a.lambda == 12 - a.mu) || (a.s_lo == a.logn - a.mu && a.lambda == 0);
 }
 
 // LDS word of point i (0..255) of the tile's transform k (0..15): one padding word per 16 points; transform-minor in the
 // first pass (a wave's lanes are 16 columns x 4 points), transform-major in the second (16 points x 4 chunks)
-template <int PASS>
+template <int PASS, int MU>
 LSA_HD int r16_lds(int k, int i) {
     const int p = i + (i >> 4);
-    return PASS == 0 ? (p << 4) + k : k * 272 + p;
+    return PASS == 0 ? (p << (12 - MU)) + k : k * ((1 << MU) + (1 << (MU - 4))) + p;
 }
 // element index inside the limb
-template <int PASS>
+template <int PASS, int MU>
 LSA_HD long long r16_x(const NttPassArgs& a, int tile, int k, int i) {
-    return PASS == 0 ? ((long long)tile << 4) + ((long long)i << (a.logn - 8)) + k : ((long long)tile << 12) + (k << 8) + i;
+    return PASS == 0 ? ((long long)tile << (12 - MU)) + ((long long)i << (a.logn - MU)) + k : ((long long)tile << 12) + (k << MU) + i;
+}
+// the e-th point a thread holds: i + 2^(MU-4) e in the strided image (first four stages), 16 i + e in the contiguous one
+template <int MU, int IMAGE>
+LSA_HD int r16_pt(int i, int e) {
+    return IMAGE == 0 ? i + (e << (MU - 4)) : 16 * i + e;
 }
 LSA_HD u64 r16_load1(const u64* p) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LSA_NTT_NO_NT)
@@ -75,45 +83,58 @@ LSA_HD R16Limb r16_limb(const NttPassArgs& a, const NttBlockCtx& bc) {
     return L;
 }
 
-// one radix-16 group on either engine, in place on the raw 64-bit images (doubles' bits on the FP64 engine)
-// hi = 0: stages s_lo .. s_lo+3 (twiddle group G1); hi = 1: stages s_lo+4 .. s_lo+7 (twiddle group (G1 << 4) + i_hi).
-// The first group of a first pass has G = 0 for every lane of the grid: its 15 twiddles are scalar loads.
-template <int PASS, int HI>
+// the radix groups of one image on either engine, in place on the raw 64-bit images (doubles' bits on the FP64 engine).
+// HI = 0: ONE radix-16 group, stages s_lo .. s_lo+3 (twiddle group G = G1); HI = 1: the last MU-4 stages on the thread's 16
+// contiguous points = 2^(8-MU) groups of radix 2^(MU-4), group g with twiddle group (G1 << 4) + (i << (8-MU)) + g (G = that of
+// g = 0).  The first group of a first pass has G = 0 for every lane of the grid: its 15 twiddles are scalar loads.
+template <int PASS, int HI, int MU>
 LSA_HD void r16_group(u64 (&v)[16], const NttPassArgs& a, const NttBlockCtx& bc, const R16Limb& L, unsigned G) {
+    constexpr int R = HI ? MU - 4 : 4, NG = 16 >> R, E = 1 << R;
     const int s_base = (PASS == 0 ? 0 : L.s_lo) + 4 * HI;
     constexpr bool TWU = PASS == 0 && HI == 0;
     const bool scale_here = PASS == 0 && HI == 0 && a.inverse && a.apply_scale;   // (the transform's stage 0 is in the first pass)
     if (bc.fp) {
-        double d[16];
-#pragma unroll
-        for (int e = 0; e < 16; e++) d[e] = d_from_bits(v[e]);
         const double sc0 = scale_here ? a.scaled[2 * bc.mod] : 0.0, sc1 = scale_here ? a.scaled[2 * bc.mod + 1] : 0.0;
-        ntt_group_fp<4, TWU>(d, a.inverse != 0, L.twd, s_base, G, L.q, L.qinv, scale_here, sc0, sc1, false);
 #pragma unroll
-        for (int e = 0; e < 16; e++) v[e] = d_to_bits(d[e]);
+        for (int g = 0; g < NG; g++) {
+            double d[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) d[e] = d_from_bits(v[g * E + e]);
+            ntt_group_fp<R, TWU>(d, a.inverse != 0, L.twd, s_base, G + (unsigned)g, L.q, L.qinv, scale_here, sc0, sc1, false);
+#pragma unroll
+            for (int e = 0; e < E; e++) v[g * E + e] = d_to_bits(d[e]);
+        }
     } else {
         const u64* sc = a.scale + 4 * bc.mod;
         const u64 sc0 = scale_here ? sc[0] : 0, sc0s = scale_here ? sc[1] : 0, sc1 = scale_here ? sc[2] : 0, sc1s = scale_here ? sc[3] : 0;
-        ntt_group_int<4, TWU>(v, a.inverse != 0, L.tw, s_base, G, L.md.q, scale_here, sc0, sc0s, sc1, sc1s);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            u64 w[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) w[e] = v[g * E + e];
+            ntt_group_int<R, TWU>(w, a.inverse != 0, L.tw, s_base, G + (unsigned)g, L.md.q, scale_here, sc0, sc0s, sc1, sc1s);
+#pragma unroll
+            for (int e = 0; e < E; e++) v[g * E + e] = w[e];
+        }
     }
 }
 
 // thread -> (transform k, index inside the group's complement) for the "stride-16" image (points i + 16 e) and the
 // "contiguous" image (points 16 i + e): the SAME split of the thread index serves both images of a pass
-template <int PASS>
+template <int PASS, int MU>
 LSA_HD void r16_lane(int tid, int& k, int& i) {
-    if (PASS == 0) {
-        k = tid & 15;
-        i = tid >> 4;
-    } else {
-        i = tid & 15;
-        k = tid >> 4;
+    if (PASS == 0) {   // 2^(12-MU) transforms (columns) side by side: consecutive lanes = consecutive columns
+        k = tid & ((1 << (12 - MU)) - 1);
+        i = tid >> (12 - MU);
+    } else {           // 2^(MU-4) lanes per transform
+        i = tid & ((1 << (MU - 4)) - 1);
+        k = tid >> (MU - 4);
     }
 }
 // twiddle group of transform k at the pass's first stage
-template <int PASS>
+template <int PASS, int MU>
 LSA_HD unsigned r16_G1(const NttBlockCtx& bc, int k) {
-    return PASS == 0 ? 0u : ((unsigned)bc.tile << 4) + (unsigned)k;
+    return PASS == 0 ? 0u : ((unsigned)bc.tile << (12 - MU)) + (unsigned)k;
 }
 
 // ---------------------------------------------------------------------------------------------- phases
@@ -122,13 +143,13 @@ LSA_HD unsigned r16_G1(const NttBlockCtx& bc, int k) {
 
 // global -> registers (stride-16 or contiguous-by-rows image; 8 bytes per lane, 16 lanes = one 128-byte line) with the
 // load-side conversions, IMAGE = 0 stride16, 1 contig (contig only ever direct in the first pass)
-template <int PASS, bool FZ, int IMAGE>
+template <int PASS, bool FZ, int IMAGE, int MU>
 LSA_HD void r16_load_direct(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64 (&v)[16]) {
     const u64* g;
     const u64* gl;
     const NttLoadFix f = ntt_make_load_fix<FZ>(a, bc, g, gl);
     int k, i;
-    r16_lane<PASS>(tid, k, i);
+    r16_lane<PASS, MU>(tid, k, i);
     u64 t[16];
     if (FZ && f.add) {
         // two operands per point (merged ModDown + rescale prologue): two rounds of eight so that 16, not 32, loads are in flight
@@ -136,7 +157,7 @@ LSA_HD void r16_load_direct(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         for (int h = 0; h < 2; h++) {
 #pragma unroll
             for (int e = 8 * h; e < 8 * h + 8; e++) {
-                const long long x = r16_x<PASS>(a, bc.tile, k, IMAGE == 0 ? i + 16 * e : 16 * i + e);
+                const long long x = r16_x<PASS, MU>(a, bc.tile, k, r16_pt<MU, IMAGE>(i, e));
                 v[e] = r16_load1(g + x);
                 t[e] = r16_load1(gl + x);
             }
@@ -146,7 +167,7 @@ LSA_HD void r16_load_direct(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         return;
     }
 #pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = r16_load1(g + r16_x<PASS>(a, bc.tile, k, IMAGE == 0 ? i + 16 * e : 16 * i + e));
+    for (int e = 0; e < 16; e++) v[e] = r16_load1(g + r16_x<PASS, MU>(a, bc.tile, k, r16_pt<MU, IMAGE>(i, e)));
     if (!(FZ && f.head)) {   // plain load: the only conversion is u64 -> double on FP64-engine limbs that are not handed over raw
         if (f.fp && !f.raw) {
 #pragma unroll
@@ -161,27 +182,27 @@ LSA_HD void r16_load_direct(const NttPassArgs& a, const NttBlockCtx& bc, int tid
 }
 // registers -> global, the mirror image (never the last pass of a forward transform in the second pass: that one needs
 // 16-byte coalesced stores and goes through r16_store_coalesced)
-template <int PASS, bool FZ, int IMAGE>
+template <int PASS, bool FZ, int IMAGE, int MU>
 LSA_HD void r16_store_direct(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64 (&v)[16]) {
     u64* g;
     const u64* pa;
     const u64* pb;
     const NttStoreFix f = ntt_make_store_fix<FZ>(a, bc, g, pa, pb);
     int k, i;
-    r16_lane<PASS>(tid, k, i);
+    r16_lane<PASS, MU>(tid, k, i);
     if (FZ && f.tail) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             u64 va[8], vb[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const long long x = r16_x<PASS>(a, bc.tile, k, IMAGE == 0 ? i + 16 * (8 * h + e) : 16 * i + 8 * h + e);
+                const long long x = r16_x<PASS, MU>(a, bc.tile, k, r16_pt<MU, IMAGE>(i, 8 * h + e));
                 va[e] = r16_load1(pa + x);
                 vb[e] = f.with_base ? r16_load1(pb + x) : 0;
             }
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const long long x = r16_x<PASS>(a, bc.tile, k, IMAGE == 0 ? i + 16 * (8 * h + e) : 16 * i + 8 * h + e);
+                const long long x = r16_x<PASS, MU>(a, bc.tile, k, r16_pt<MU, IMAGE>(i, 8 * h + e));
                 r16_store1(g + x, ntt_store_fix(f, v[8 * h + e], va[e], vb[e]));
             }
         }
@@ -200,33 +221,34 @@ LSA_HD void r16_store_direct(const NttPassArgs& a, const NttBlockCtx& bc, int ti
         for (int e = 0; e < 16; e++) w[e] = ntt_store_fix(f, v[e], 0, 0);
     }
 #pragma unroll
-    for (int e = 0; e < 16; e++) r16_store1(g + r16_x<PASS>(a, bc.tile, k, IMAGE == 0 ? i + 16 * e : 16 * i + e), w[e]);
+    for (int e = 0; e < 16; e++) r16_store1(g + r16_x<PASS, MU>(a, bc.tile, k, r16_pt<MU, IMAGE>(i, e)), w[e]);
 }
 // LDS exchange
-template <int PASS, int IMAGE>
+template <int PASS, int IMAGE, int MU>
 LSA_HD void r16_lds_put(int tid, u64* lds, const u64 (&v)[16]) {
     int k, i;
-    r16_lane<PASS>(tid, k, i);
+    r16_lane<PASS, MU>(tid, k, i);
 #pragma unroll
-    for (int e = 0; e < 16; e++) lds[r16_lds<PASS>(k, IMAGE == 0 ? i + 16 * e : 16 * i + e)] = v[e];
+    for (int e = 0; e < 16; e++) lds[r16_lds<PASS, MU>(k, r16_pt<MU, IMAGE>(i, e))] = v[e];
 }
-template <int PASS, int IMAGE>
+template <int PASS, int IMAGE, int MU>
 LSA_HD void r16_lds_get(int tid, const u64* lds, u64 (&v)[16]) {
     int k, i;
-    r16_lane<PASS>(tid, k, i);
+    r16_lane<PASS, MU>(tid, k, i);
 #pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = lds[r16_lds<PASS>(k, IMAGE == 0 ? i + 16 * e : 16 * i + e)];
+    for (int e = 0; e < 16; e++) v[e] = lds[r16_lds<PASS, MU>(k, r16_pt<MU, IMAGE>(i, e))];
 }
 // second pass: the tile's 4096 consecutive points as 16-byte pairs, wave w owning chunks 4w .. 4w+3 (the ones its lanes
 // transform): pair p = lane + 64 m of the wave's 512 pairs
+template <int MU>
 LSA_HD void r16_pair_pos(int tid, int m, int& k, int& i) {
     const int wave = tid >> 6, lane = tid & 63;
     const int c = 2 * (lane + 64 * m);   // element inside the wave's 1024
-    k = 4 * wave + (c >> 8);
-    i = c & 255;
+    k = (wave << (10 - MU)) + (c >> MU);
+    i = c & ((1 << MU) - 1);
 }
 // second pass, inverse: 16-byte coalesced loads -> LDS (contiguous image is read back from there)
-template <bool FZ>
+template <bool FZ, int MU>
 LSA_HD void r16_load_coalesced(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds) {
     const u64* g;
     const u64* gl;
@@ -236,19 +258,19 @@ LSA_HD void r16_load_coalesced(const NttPassArgs& a, const NttBlockCtx& bc, int 
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         int k, i;
-        r16_pair_pos(tid, m, k, i);
-        ntt_load_data_pair(g + r16_x<1>(a, bc.tile, k, i), st[2 * m], st[2 * m + 1]);
+        r16_pair_pos<MU>(tid, m, k, i);
+        ntt_load_data_pair(g + r16_x<1, MU>(a, bc.tile, k, i), st[2 * m], st[2 * m + 1]);
     }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         int k, i;
-        r16_pair_pos(tid, m, k, i);
-        lds[r16_lds<1>(k, i)] = ntt_load_fix(f, st[2 * m], st[2 * m]);
-        lds[r16_lds<1>(k, i + 1)] = ntt_load_fix(f, st[2 * m + 1], st[2 * m + 1]);
+        r16_pair_pos<MU>(tid, m, k, i);
+        lds[r16_lds<1, MU>(k, i)] = ntt_load_fix(f, st[2 * m], st[2 * m]);
+        lds[r16_lds<1, MU>(k, i + 1)] = ntt_load_fix(f, st[2 * m + 1], st[2 * m + 1]);
     }
 }
 // second pass, forward: LDS -> 16-byte coalesced stores with the store-side conversions and the fused epilogue
-template <bool FZ>
+template <bool FZ, int MU>
 LSA_HD void r16_store_coalesced(const NttPassArgs& a, const NttBlockCtx& bc, int tid, const u64* lds) {
     u64* g;
     const u64* pa;
@@ -261,10 +283,10 @@ LSA_HD void r16_store_coalesced(const NttPassArgs& a, const NttBlockCtx& bc, int
 #pragma unroll
         for (int m = 0; m < LSA_NTT_STORE_CHUNK; m++) {
             int k, i;
-            r16_pair_pos(tid, m0 + m, k, i);
-            xs[m] = r16_x<1>(a, bc.tile, k, i);
-            v[2 * m] = lds[r16_lds<1>(k, i)];
-            v[2 * m + 1] = lds[r16_lds<1>(k, i + 1)];
+            r16_pair_pos<MU>(tid, m0 + m, k, i);
+            xs[m] = r16_x<1, MU>(a, bc.tile, k, i);
+            v[2 * m] = lds[r16_lds<1, MU>(k, i)];
+            v[2 * m + 1] = lds[r16_lds<1, MU>(k, i + 1)];
             va[2 * m] = va[2 * m + 1] = vb[2 * m] = vb[2 * m + 1] = 0;
             if (FZ && f.tail) ntt_load_data_pair(pa + xs[m], va[2 * m], va[2 * m + 1]);
             if (FZ && f.with_base) ntt_load_data_pair(pb + xs[m], vb[2 * m], vb[2 * m + 1]);
@@ -280,37 +302,37 @@ LSA_HD void r16_store_coalesced(const NttPassArgs& a, const NttBlockCtx& bc, int
 // ordering point in the second (kernels.hip); the CPU replay runs each phase for every thread in turn.
 //   forward: [0] load stride16, group LO, put stride16   | [1] get contig, group HI, (PASS 0: store contig) (PASS 1: put contig) | [2] PASS 1: coalesced store
 //   inverse: [0] (PASS 0: load contig) (PASS 1: coalesced load -> LDS) | [1] (PASS 1: get contig) group HI, put contig | [2] get stride16, group LO, store stride16
-template <int PASS, int FZ>
+template <int PASS, int FZ, int MU>
 LSA_HD void r16_phase(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int phase, u64 (&v)[16]) {
     const R16Limb L = r16_limb(a, bc);
     int k, i;
-    r16_lane<PASS>(tid, k, i);
-    const unsigned G1 = r16_G1<PASS>(bc, k), G2 = (G1 << 4) + (unsigned)i;
+    r16_lane<PASS, MU>(tid, k, i);
+    const unsigned G1 = r16_G1<PASS, MU>(bc, k), G2 = (G1 << 4) + ((unsigned)i << (8 - MU));
     if (!a.inverse) {
         if (phase == 0) {
-            r16_load_direct<PASS, (FZ & 1) != 0, 0>(a, bc, tid, v);
-            r16_group<PASS, 0>(v, a, bc, L, G1);
-            r16_lds_put<PASS, 0>(tid, lds, v);
+            r16_load_direct<PASS, (FZ & 1) != 0, 0, MU>(a, bc, tid, v);
+            r16_group<PASS, 0, MU>(v, a, bc, L, G1);
+            r16_lds_put<PASS, 0, MU>(tid, lds, v);
         } else if (phase == 1) {
-            r16_lds_get<PASS, 1>(tid, lds, v);
-            r16_group<PASS, 1>(v, a, bc, L, G2);
-            if (PASS == 0) r16_store_direct<PASS, (FZ & 2) != 0, 1>(a, bc, tid, v);
-            else r16_lds_put<PASS, 1>(tid, lds, v);
+            r16_lds_get<PASS, 1, MU>(tid, lds, v);
+            r16_group<PASS, 1, MU>(v, a, bc, L, G2);
+            if (PASS == 0) r16_store_direct<PASS, (FZ & 2) != 0, 1, MU>(a, bc, tid, v);
+            else r16_lds_put<PASS, 1, MU>(tid, lds, v);
         } else if (PASS == 1) {
-            r16_store_coalesced<(FZ & 2) != 0>(a, bc, tid, lds);
+            r16_store_coalesced<(FZ & 2) != 0, MU>(a, bc, tid, lds);
         }
     } else {
         if (phase == 0) {
-            if (PASS == 0) r16_load_direct<PASS, false, 1>(a, bc, tid, v);
-            else r16_load_coalesced<false>(a, bc, tid, lds);
+            if (PASS == 0) r16_load_direct<PASS, false, 1, MU>(a, bc, tid, v);
+            else r16_load_coalesced<false, MU>(a, bc, tid, lds);
         } else if (phase == 1) {
-            if (PASS == 1) r16_lds_get<PASS, 1>(tid, lds, v);
-            r16_group<PASS, 1>(v, a, bc, L, G2);
-            r16_lds_put<PASS, 1>(tid, lds, v);
+            if (PASS == 1) r16_lds_get<PASS, 1, MU>(tid, lds, v);
+            r16_group<PASS, 1, MU>(v, a, bc, L, G2);
+            r16_lds_put<PASS, 1, MU>(tid, lds, v);
         } else {
-            r16_lds_get<PASS, 0>(tid, lds, v);
-            r16_group<PASS, 0>(v, a, bc, L, G1);
-            r16_store_direct<PASS, false, 0>(a, bc, tid, v);
+            r16_lds_get<PASS, 0, MU>(tid, lds, v);
+            r16_group<PASS, 0, MU>(v, a, bc, L, G1);
+            r16_store_direct<PASS, false, 0, MU>(a, bc, tid, v);
         }
     }
 }

@@ -73,10 +73,10 @@ def test_fp64_engine_matches_oracle(emu, logn, tau):
     _check(emu, logn, tau, mods, fp64=3)   # the interleaved workgroup order of mixed-engine launches
 
 
-@pytest.mark.parametrize("logn", [15, 16, 17])
+@pytest.mark.parametrize("logn", [14, 15, 16, 17])
 def test_radix16_squared_passes_match_oracle(emu, logn):
-    """the 8-stage passes of two-pass plans through ntt_r16.h (both passes at N = 2^16, the second at 2^15, the first at 2^17;
-    the other pass of those rings stays on the staged kernel): both engines, forward and inverse, raw FP64 hand-off"""
+    """the 8- and 7-stage passes of two-pass plans through ntt_r16.h (both passes at N = 2^14 .. 2^16, the first at 2^17 -- its
+    9-stage second pass stays on the staged kernel): both engines, forward and inverse, raw FP64 hand-off"""
     D = params.CKKS_DEFAULT[65536]
     B = params.CKKS_BOOTSTRAP_65536
     if logn == 17:

@@ -12,8 +12,9 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["lattisense_amd/csrc/kernels.hip", "lattisense_amd/csrc/ntt_core.h", "lattisense_amd/csrc/modarith.h",
-                  "lattisense_amd/csrc/ops.hip"]
+KERNEL_SOURCES = ["lattisense_amd/csrc/kernels.hip", "lattisense_amd/csrc/ntt_core.h", "lattisense_amd/csrc/ntt_r16.h",
+                  "lattisense_amd/csrc/modarith.h", "lattisense_amd/csrc/ops.hip"]
+NTT_KERNELS = ("k_ntt_r16", "k_ntt_pass")   # the limb-transform passes: radix-16-squared (8-stage passes) and the staged kernel
 
 
 def sources_hash():
@@ -46,7 +47,7 @@ def main(d, out_dir, workload="ckks_hmult", batch=256):
         f, w = fetch.get(k, [0.0]), write.get(k, [0.0])
         kernels[short(k)] = {"launches": len(f), "fetch_size_kb_mean": sum(f) / len(f), "write_size_kb_mean": sum(w) / len(w),
                              "hbm_bytes_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1e3}
-    ntt = {k: v for k, v in kernels.items() if k.startswith("k_ntt_pass")}
+    ntt = {k: v for k, v in kernels.items() if k.startswith(NTT_KERNELS)}
     launches = sum(v["launches"] for v in ntt.values())
     weighted = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ntt.values()) / max(launches, 1)
     bench = {}
@@ -65,8 +66,8 @@ def main(d, out_dir, workload="ckks_hmult", batch=256):
     if "k_ntt_pass" in alg:
         ratios["k_ntt_pass"] = {"counter_bytes_per_launch": weighted, "algorithmic_bytes_per_launch": alg["k_ntt_pass"],
                                 "ratio": weighted / alg["k_ntt_pass"]}
-    res = {"kernel": "k_ntt_pass (all variants, launch-weighted)", "workload": workload, "batch": int(batch), "variants": ntt,
-           "hbm_bytes_per_launch": weighted, "other_kernels": {k: v for k, v in kernels.items() if not k.startswith("k_ntt_pass")},
+    res = {"kernel": "k_ntt_r16 + k_ntt_pass (every limb-transform pass, launch-weighted)", "workload": workload, "batch": int(batch), "variants": ntt,
+           "hbm_bytes_per_launch": weighted, "other_kernels": {k: v for k, v in kernels.items() if not k.startswith(NTT_KERNELS)},
            "counter_vs_algorithmic": ratios,
            "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE exact; units KB",
            "kernel_sources_sha256": sources_hash(), "source": "tools/profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py " + workload}

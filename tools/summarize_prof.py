@@ -12,8 +12,9 @@ def find(d, pat):
 
 def short(name):
     n = name.split("(")[0]
-    if "k_ntt_pass" in n:   # keep the variant: k_ntt_pass<false> (plain) / k_ntt_pass<true> (fused tails)
-        return n[n.index("k_ntt_pass"):]
+    for fam in ("k_ntt_r16", "k_ntt_pass"):   # keep the variant (template arguments)
+        if fam in n:
+            return n[n.index(fam):]
     for k in ("k_ntt_pass", "k_baseconv", "k_ks_mac", "k_tensor", "k_sub_mul", "k_rescale_prep", "k_permute",
               "k_copy_rows", "k_elementwise", "k_to_mont"):
         if k in n:
@@ -29,11 +30,11 @@ def main(d):
             print("%-18s calls=%-7s total_ms=%-10.3f avg_us=%-9.3f pct=%s" % (
                 short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
                 r["Percentage"]))
-        ntt = [r for r in rows if "k_ntt_pass" in r["Name"]]
+        ntt = [r for r in rows if "k_ntt_pass" in r["Name"] or "k_ntt_r16" in r["Name"]]
         if ntt:   # both variants together: the figure bench.py's roofline.avg_launch_us is compared with
             calls = sum(int(r["Calls"]) for r in ntt)
             tot = sum(float(r["TotalDurationNs"]) for r in ntt)
-            print("%-18s calls=%-7d total_ms=%-10.3f avg_us=%-9.3f (all variants)" % ("k_ntt_pass", calls, tot / 1e6, tot / calls / 1e3))
+            print("%-18s calls=%-7d total_ms=%-10.3f avg_us=%-9.3f (all variants)" % ("k_ntt_* (passes)", calls, tot / 1e6, tot / calls / 1e3))
     for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
         files = find(os.path.join(d, sub), "*counter_collection.csv")
         if not files:
