@@ -298,6 +298,43 @@ LSA_HD void r16_store_coalesced(const NttPassArgs& a, const NttBlockCtx& bc, int
     }
 }
 
+// ---- A/B build (-DLSA_AB_DPP_LO): the first four stages of a second pass (FP64 engine, forward, MU = 8) as CROSS-LANE
+// butterflies -- the wavefront-shuffle formulation: every lane keeps its 16 consecutive points for the whole pass, the
+// partner of a stage sits 8 / 4 / 2 / 1 lanes away in the 16-lane row (DPP row_ror / quad_perm moves), both lanes of a pair
+// compute the twiddle product.  It needs the consecutive-points image from the start, i.e. a coalesced load staged through
+// LDS instead of the direct strided load, and ~14 instead of 4 vector instructions per point and stage.  Measured against the
+// register/LDS formulation in profiles/r03/ab_ntt_dpp_last_stages.log; not part of the product build.
+#if defined(LSA_AB_DPP_LO) && defined(__HIP_DEVICE_COMPILE__)
+template <int D>
+__device__ __forceinline__ int r16_dpp_xor32(int v) {
+    if (D == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    if (D == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    if (D == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    int r = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xA, false);              // banks 1,3 (bit 2 set): from lane - 4 (row_ror:4)
+    return __builtin_amdgcn_update_dpp(r, v, 0x12C, 0xF, 0x5, false);               // banks 0,2: from lane + 4 (row_ror:12)
+}
+template <int D>
+__device__ __forceinline__ double r16_dpp_xor(double x) {
+    const u64 b = d_to_bits(x);
+    const u32 lo = (u32)r16_dpp_xor32<D>((int)(u32)b), hi = (u32)r16_dpp_xor32<D>((int)(u32)(b >> 32));
+    return d_from_bits(((u64)hi << 32) | lo);
+}
+template <int J>
+__device__ __forceinline__ void r16_dpp_stage(double (&v)[16], const double* twd, int s_lo, unsigned G1, int i_hi, double q, double qinv) {
+    constexpr int D = 8 >> J;
+    const int s = s_lo + J, kk = i_hi >> (4 - J);
+    const double w = (twd + (1LL << s))[ntt_tw_pos_fp(s, J, G1, kk)];
+    const bool upper = (i_hi >> (3 - J)) & 1;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const double X = v[e], P = r16_dpp_xor<D>(X);
+        const double U = upper ? P : X, V = upper ? X : P;
+        const double T = fp_modmul(V, w, q, qinv);
+        v[e] = upper ? U - T : U + T;
+    }
+}
+#endif
+
 // The phases of a pass, in execution order; `sync` between them is a workgroup barrier in the first pass and a wavefront-local
 // ordering point in the second (kernels.hip); the CPU replay runs each phase for every thread in turn.
 //   forward: [0] load stride16, group LO, put stride16   | [1] get contig, group HI, (PASS 0: store contig) (PASS 1: put contig) | [2] PASS 1: coalesced store
@@ -308,6 +345,29 @@ LSA_HD void r16_phase(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64*
     int k, i;
     r16_lane<PASS, MU>(tid, k, i);
     const unsigned G1 = r16_G1<PASS, MU>(bc, k), G2 = (G1 << 4) + ((unsigned)i << (8 - MU));
+#if defined(LSA_AB_DPP_LO) && defined(__HIP_DEVICE_COMPILE__)
+    if (PASS == 1 && MU == 8 && !a.inverse && bc.fp) {   // A/B: cross-lane first four stages (see above)
+        if (phase == 0) {
+            r16_load_coalesced<false, MU>(a, bc, tid, lds);
+        } else if (phase == 1) {
+            r16_lds_get<PASS, 1, MU>(tid, lds, v);
+            double d[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) d[e] = d_from_bits(v[e]);
+            r16_dpp_stage<0>(d, L.twd, L.s_lo, G1, i, L.q, L.qinv);
+            r16_dpp_stage<1>(d, L.twd, L.s_lo, G1, i, L.q, L.qinv);
+            r16_dpp_stage<2>(d, L.twd, L.s_lo, G1, i, L.q, L.qinv);
+            r16_dpp_stage<3>(d, L.twd, L.s_lo, G1, i, L.q, L.qinv);
+#pragma unroll
+            for (int e = 0; e < 16; e++) v[e] = d_to_bits(d[e]);
+            r16_group<PASS, 1, MU>(v, a, bc, L, G2);
+            r16_lds_put<PASS, 1, MU>(tid, lds, v);
+        } else {
+            r16_store_coalesced<(FZ & 2) != 0, MU>(a, bc, tid, lds);
+        }
+        return;
+    }
+#endif
     if (!a.inverse) {
         if (phase == 0) {
             r16_load_direct<PASS, (FZ & 1) != 0, 0, MU>(a, bc, tid, v);
