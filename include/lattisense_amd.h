@@ -151,6 +151,12 @@ int lsa_ckks_rotate_many(lsa_context ctx, int level, const uint64_t* in, int n_r
 typedef struct lsa_bootstrap_st* lsa_bootstrap;
 int lsa_bootstrap_create(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
                          double in_scale, double out_scale, int log_slots, void* stream, lsa_bootstrap* out);
+/* the same with the EvalMod polynomial degrees the reference forwards (gpu_wrapper.cu:100-103): sine_deg 1..63 (the cosine
+ * interpolant takes ceil(log2(sine_deg+1)) levels), arcsine_deg 0 (none) or odd <= 15 (ceil(log2(arcsine_deg+1)) more levels) */
+int lsa_bootstrap_create_ex(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
+                            double in_scale, double out_scale, int log_slots, int sine_deg, int arcsine_deg, void* stream,
+                            lsa_bootstrap* out);
+int lsa_bootstrap_evalmod_constants(lsa_bootstrap b, int* n_cheb, double* cheb, int* n_asin, double* asin_coef);
 void lsa_bootstrap_destroy(lsa_bootstrap b);
 int lsa_bootstrap_info(lsa_bootstrap b, int* out_level, double* out_scale, int* n_galois, int* n_matrices, int* n_cts,
                        int* sparse);

@@ -83,6 +83,10 @@ SIGNATURES = {
                                      ctypes.c_longlong, ctypes.c_longlong, c_vp]),
     "lsa_bootstrap_create": (c_int, [c_vp, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int,
                                      c_vp, ctypes.POINTER(c_vp)]),
+    "lsa_bootstrap_create_ex": (c_int, [c_vp, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int,
+                                        c_int, c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "lsa_bootstrap_evalmod_constants": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
+                                                ctypes.POINTER(ctypes.c_double)]),
     "lsa_bootstrap_destroy": (None, [c_vp]),
     "lsa_bootstrap_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
                                    ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

@@ -237,7 +237,11 @@ struct Bootstrap {
     bool sparse = false;
     std::vector<BtMatrix> cts, stc;
     BtMatrix p1, p2;                     // sparse: last CoeffsToSlots matrix split for x and conj(x), real | imaginary halves
-    std::vector<double> cheb;            // 32 Chebyshev coefficients of cos(2 pi (K x - 1/4) / 2^r) on [-1,1]
+    std::vector<double> cheb;            // 2^cheb_depth Chebyshev coefficients of cos(2 pi (K x - 1/4) / 2^r) on [-1,1]
+    int sine_deg = 30, arcsine_deg = 0;  // reference: btp_eval_mod_sine_deg / _arcsine_deg (gpu_wrapper.cu:100-103)
+    int cheb_depth = 5, asin_depth = 0;  // levels of the cosine interpolant (ceil log2(sine_deg + 1)) and of the arcsine polynomial
+    std::vector<double> asin_coef;       // arcsine Taylor coefficients in the monomial basis, padded to 2^asin_depth (empty: none)
+    int evalmod_depth() const { return cheb_depth + r + asin_depth; }
     u64* mono[2] = {nullptr, nullptr};   // NTT of +X^(N/2) and -X^(N/2), [top_level+1][N]
     std::vector<u64> galois;             // Galois elements a run needs (rotations + conjugation)
     long long mul_c = 1;                 // integer scale-up factor
@@ -287,12 +291,13 @@ struct Bootstrap {
     }
 
     double evalmod_out_scale(int level_in) const {
-        int level = level_in - 5;
+        int level = level_in - cheb_depth;
         double sc = (double)c.T.mod[level + 1];
         for (int i = 0; i < r; i++) {
             sc = sc * sc / (double)c.T.mod[level];
             level--;
         }
+        if (asin_depth) sc = (double)c.T.mod[level - asin_depth + 1];   // a polynomial evaluation ends at the scale of the prime above its result
         return sc;
     }
 
@@ -300,13 +305,22 @@ struct Bootstrap {
         const int n = c.n / 2;
         top_level = c.nq - 1;
         LSA_REQUIRE(c.algo == LSA_ALGO_CKKS, "bootstrap: CKKS only");
-        LSA_REQUIRE(top_level - cts_depth - 5 - r - stc_depth >= 0, "bootstrap: modulus chain too short");
+        LSA_REQUIRE(sine_deg >= 1 && sine_deg <= 63, "bootstrap: sine degree outside 1..63");
+        LSA_REQUIRE(arcsine_deg >= 0 && arcsine_deg <= 15 && (arcsine_deg == 0 || (arcsine_deg & 1)), "bootstrap: arcsine degree must be odd and at most 15");
+        cheb_depth = 1;
+        while ((1 << cheb_depth) < sine_deg + 1) cheb_depth++;
+        asin_depth = 0;
+        if (arcsine_deg > 0) {
+            asin_depth = 1;
+            while ((1 << asin_depth) < arcsine_deg + 1) asin_depth++;
+        }
+        LSA_REQUIRE(top_level - cts_depth - evalmod_depth() - stc_depth >= 0, "bootstrap: modulus chain too short");
         const std::vector<int> rg = rot_group(n);
         const double q0 = (double)c.T.mod[0];
         mul_c = std::max<long long>(1, round_even(q0 / (mr * in_scale)));
         d1 = in_scale * (double)mul_c;
         const int evalmod_level = top_level - cts_depth;
-        const int stc_level = evalmod_level - 5 - r;
+        const int stc_level = evalmod_level - evalmod_depth();
         natural_scale = evalmod_out_scale(evalmod_level) * 2.0 * kPi * d1 / q0;
         int logn_ring = 0;
         while ((1 << logn_ring) < c.n) logn_ring++;
@@ -421,8 +435,22 @@ struct Bootstrap {
         for (size_t i = 0; i < ms.size(); i++) stc.push_back(make_one(ms[i], stc_level - (int)i, sparse && i == 0 ? 2 * ns : ns));
         gal[2ULL * c.n - 1] = true;
         for (auto& kv : gal) galois.push_back(kv.first);
-        // Chebyshev interpolant (first-kind nodes) of cos(2 pi (K x - 1/4) / 2^r), 32 coefficients
-        const int M = 32;
+        // arcsine correction (btp_eval_mod_arcsine_deg > 0): after the double-angle steps y = sin(2 pi v); arcsin(y) = 2 pi eps exactly
+        // where sin only approximates it -- Taylor series sum_k C(2k,k) / (4^k (2k+1)) y^(2k+1) up to the requested degree
+        asin_coef.clear();
+        if (asin_depth) {
+            asin_coef.assign((size_t)1 << asin_depth, 0.0);
+            double binom = 1.0, pow4 = 1.0;   // C(2k, k), 4^k
+            for (int k = 0; 2 * k + 1 <= arcsine_deg; k++) {
+                if (k > 0) {
+                    binom = binom * (double)(2 * k) * (double)(2 * k - 1) / ((double)k * (double)k);
+                    pow4 *= 4.0;
+                }
+                asin_coef[(size_t)(2 * k + 1)] = binom / (pow4 * (double)(2 * k + 1));
+            }
+        }
+        // Chebyshev interpolant (first-kind nodes) of cos(2 pi (K x - 1/4) / 2^r), 2^cheb_depth coefficients
+        const int M = 1 << cheb_depth;
         cheb.assign(M, 0.0);
         std::vector<double> f(M), th(M);
         for (int j = 0; j < M; j++) {
@@ -763,9 +791,41 @@ struct Eval {
         return rec(coeffs, level_out, q(level_out + 1));
     }
 
+    // sum_k coeffs[k] u^k, len(coeffs) a power of two: the same binary splitting in the monomial basis (p = hi * u^half + lo)
+    DCt eval_monomial(const DCt& u, const std::vector<double>& coeffs) {
+        int k = 0;
+        while ((1u << k) < coeffs.size()) k++;
+        std::map<int, DCt> powers;
+        powers[1] = u;
+        for (int j = 1; j < k; j++) {
+            const DCt& p = powers[1 << (j - 1)];
+            powers[1 << j] = mul(p, p);
+        }
+        std::function<DCt(const std::vector<double>&, int, double)> rec = [&](const std::vector<double>& cf, int level_out,
+                                                                              double scale_out) -> DCt {
+            if (cf.size() == 2) {
+                DCt t1 = drop(u, level_out + 1);
+                const double cs = scale_out * q(level_out + 1) / t1.scale;
+                DCt rr = rescale(mul_const(t1, cf[1], cs));
+                rr.scale = scale_out;
+                return add_const(rr, cf[0]);
+            }
+            const size_t half = cf.size() / 2;
+            std::vector<double> hi(cf.begin() + half, cf.end()), lo(cf.begin(), cf.begin() + half);
+            DCt th = drop(powers[(int)half], level_out + 1);
+            DCt h = rec(hi, level_out + 1, scale_out * q(level_out + 1) / th.scale);
+            DCt prod = mul(h, th);
+            prod.scale = scale_out;
+            return add(prod, rec(lo, level_out, scale_out));
+        };
+        const int level_out = u.level - k;
+        return rec(coeffs, level_out, q(level_out + 1));
+    }
+
     DCt eval_mod(const DCt& u) {
         DCt y = eval_chebyshev(u, bt.cheb);
         for (int i = 0; i < bt.r; i++) y = mul_int_add_const(mul(y, y), 2, -1.0);
+        if (!bt.asin_coef.empty()) y = eval_monomial(y, bt.asin_coef);
         return y;
     }
 
@@ -787,8 +847,10 @@ struct Eval {
 }  // namespace
 
 Bootstrap* bootstrap_create(Context& c, int cts_depth, int stc_depth, int K, int double_angle, double message_ratio,
-                            double in_scale, double out_scale, int log_slots, hipStream_t s) {
+                            double in_scale, double out_scale, int log_slots, hipStream_t s, int sine_deg, int arcsine_deg) {
     auto b = std::make_unique<Bootstrap>(c);
+    b->sine_deg = sine_deg;
+    b->arcsine_deg = arcsine_deg;
     b->log_slots = log_slots;
     b->cts_depth = cts_depth;
     b->stc_depth = stc_depth;
@@ -890,12 +952,13 @@ void bootstrap_run(Bootstrap& bt, const u64* in, long long sin, u64* out, long l
     launch_copy_rows(c, y.data(), ev.stride(y.level), out, sout, (int)all.size(), all.data(), batch, s);
 }
 
-int bootstrap_out_level(const Bootstrap& bt) { return bt.top_level - bt.cts_depth - 5 - bt.r - bt.stc_depth; }
+int bootstrap_out_level(const Bootstrap& bt) { return bt.top_level - bt.cts_depth - bt.evalmod_depth() - bt.stc_depth; }
 
 // read-only views for the C API (constants are exported so that the oracle can replay the program with the same integers)
 double bootstrap_out_scale(const Bootstrap& bt) { return bt.natural_scale; }
 const std::vector<u64>& bootstrap_galois(const Bootstrap& bt) { return bt.galois; }
 const std::vector<double>& bootstrap_chebyshev(const Bootstrap& bt) { return bt.cheb; }
+const std::vector<double>& bootstrap_arcsine(const Bootstrap& bt) { return bt.asin_coef; }
 // matrix order: the leading CoeffsToSlots matrices, (sparse packing: P1, P2,) the SlotsToCoeffs matrices
 int bootstrap_matrices(const Bootstrap& bt) { return (int)(bt.cts.size() + bt.stc.size()) + (bt.sparse ? 2 : 0); }
 int bootstrap_cts_matrices(const Bootstrap& bt) { return (int)bt.cts.size(); }

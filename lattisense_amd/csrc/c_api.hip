@@ -376,16 +376,36 @@ struct lsa_bootstrap_st {
     Bootstrap* b;
     Context* c;
 };
-int lsa_bootstrap_create(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
-                         double in_scale, double out_scale, int log_slots, void* stream, lsa_bootstrap* out) {
+int lsa_bootstrap_create_ex(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
+                            double in_scale, double out_scale, int log_slots, int sine_deg, int arcsine_deg, void* stream,
+                            lsa_bootstrap* out) {
     return guard([&] {
         LSA_REQUIRE(out != nullptr, "null argument");
         LSA_REQUIRE(k >= 1 && double_angle >= 0 && double_angle <= 8 && message_ratio > 0 && in_scale > 0, "bad bootstrap parameters");
         auto h = std::make_unique<lsa_bootstrap_st>();
         h->c = &C(ctx);
         LSA_REQUIRE(log_slots >= 0 && (log_slots == 0 || (2 << log_slots) <= C(ctx).n), "bad slot count");
-        h->b = bootstrap_create(C(ctx), cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale, log_slots, S(stream));
+        h->b = bootstrap_create(C(ctx), cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale, log_slots, S(stream),
+                                sine_deg, arcsine_deg);
         *out = h.release();
+    });
+}
+int lsa_bootstrap_create(lsa_context ctx, int cts_depth, int stc_depth, int k, int double_angle, double message_ratio,
+                         double in_scale, double out_scale, int log_slots, void* stream, lsa_bootstrap* out) {
+    // the reference's default EvalMod: sine degree 30 (32 Chebyshev coefficients), no arcsine (frontend/custom_task.py:443-453)
+    return lsa_bootstrap_create_ex(ctx, cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale, log_slots, 30, 0, stream, out);
+}
+// polynomial constants of the plan's EvalMod: n_cheb Chebyshev coefficients, n_asin monomial coefficients of the arcsine
+// correction (0: none); either output pointer may be null to query the counts
+int lsa_bootstrap_evalmod_constants(lsa_bootstrap b, int* n_cheb, double* cheb, int* n_asin, double* asin_coef) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr, "null bootstrap handle");
+        const auto& c = bootstrap_chebyshev(*b->b);
+        const auto& a = bootstrap_arcsine(*b->b);
+        if (n_cheb) *n_cheb = (int)c.size();
+        if (n_asin) *n_asin = (int)a.size();
+        if (cheb) std::copy(c.begin(), c.end(), cheb);
+        if (asin_coef) std::copy(a.begin(), a.end(), asin_coef);
     });
 }
 void lsa_bootstrap_destroy(lsa_bootstrap b) {
@@ -417,7 +437,8 @@ int lsa_bootstrap_chebyshev(lsa_bootstrap b, double* out32) {
     return guard([&] {
         LSA_REQUIRE(b != nullptr && out32 != nullptr, "null argument");
         const auto& cf = bootstrap_chebyshev(*b->b);
-        for (size_t i = 0; i < cf.size(); i++) out32[i] = cf[i];
+        LSA_REQUIRE(cf.size() <= 32, "more than 32 Chebyshev coefficients: use lsa_bootstrap_evalmod_constants");
+        for (size_t i = 0; i < 32; i++) out32[i] = i < cf.size() ? cf[i] : 0.0;
     });
 }
 int lsa_bootstrap_matrix_info(lsa_bootstrap b, int index, int* level, int* n1, int* n_diagonals, int* diagonals, int capacity) {

@@ -283,7 +283,8 @@ void launch_probe_mulhi(u64* buf, size_t n, int iters, hipStream_t s);
 // ---------------------------------------------------------------- CKKS bootstrapping (bootstrap.hip)
 struct Bootstrap;
 Bootstrap* bootstrap_create(Context& c, int cts_depth, int stc_depth, int K, int double_angle, double message_ratio,
-                            double in_scale, double out_scale, int log_slots, hipStream_t s);
+                            double in_scale, double out_scale, int log_slots, hipStream_t s, int sine_deg = 30, int arcsine_deg = 0);
+const std::vector<double>& bootstrap_arcsine(const Bootstrap& bt);
 bool bootstrap_is_sparse(const Bootstrap& bt);
 void bootstrap_destroy(Bootstrap* b);
 int bootstrap_out_level(const Bootstrap& bt);

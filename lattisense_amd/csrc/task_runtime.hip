@@ -341,22 +341,26 @@ struct fhe_task_handle_st {
         if (it != bootstrap_plans.end()) return *it->second;
         const mjson::Value& P = g.parameter;
         LSA_REQUIRE(P.contains("btp_output_level"), "bootstrap node in a task without bootstrapping parameters");
-        LSA_REQUIRE(P["btp_eval_mod_sine_type"].as_string() == "Cos1" && P["btp_eval_mod_arcsine_deg"].as_int() == 0,
-                    "bootstrap: only the Cos1 sine type without arcsine is implemented");
+        // (the sine TYPE is not among the fields the reference forwards to its GPU library, gpu_wrapper.cu:94-103; Cos1 is what the
+        // frontend's parameter sets say and what is implemented)
+        LSA_REQUIRE(!P.contains("btp_eval_mod_sine_type") || P["btp_eval_mod_sine_type"].as_string() == "Cos1",
+                    "bootstrap: only the Cos1 sine type is implemented");
+        const int sine_deg = (int)P["btp_eval_mod_sine_deg"].as_int(), arcsine_deg = (int)P["btp_eval_mod_arcsine_deg"].as_int();
         int log_slots = 0;
         if (P.contains("slots")) {
             const long long slots = P["slots"].as_int();
             LSA_REQUIRE(slots >= 2 && slots <= c.n / 2 && (slots & (slots - 1)) == 0, "bootstrap: slot count must be a power of two <= N/2");
             while ((1LL << log_slots) < slots) log_slots++;
         }
-        LSA_REQUIRE(P["btp_eval_mod_sine_deg"].as_int() <= 31, "bootstrap: sine degree above 31 is not implemented");
+        LSA_REQUIRE(sine_deg >= 1 && sine_deg <= 63, "bootstrap: sine degree outside 1..63");
+        LSA_REQUIRE(arcsine_deg >= 0 && arcsine_deg <= 15 && (arcsine_deg == 0 || (arcsine_deg & 1)), "bootstrap: arcsine degree must be 0 or odd and at most 15");
         const int cts_depth = (int)P["btp_cts_depth"].as_int(), stc_depth = (int)P["btp_stc_depth"].as_int();
         LSA_REQUIRE(P["btp_cts_start_level"].as_int() == c.nq - 1 && P["btp_eval_mod_start_level"].as_int() == c.nq - 1 - cts_depth,
                     "bootstrap: level plan differs from the one implemented");
         const double scale = P["scale"].as_double();
         Bootstrap* b = bootstrap_create(c, cts_depth, stc_depth, (int)P["btp_eval_mod_k"].as_int(),
                                         (int)P["btp_eval_mod_double_angle"].as_int(), P["btp_eval_mod_message_ratio"].as_double(),
-                                        scale, scale, log_slots, s);
+                                        scale, scale, log_slots, s, sine_deg, arcsine_deg);
         LSA_REQUIRE(bootstrap_out_level(*b) == P["btp_output_level"].as_int() &&
                         P["btp_stc_start_level"].as_int() == bootstrap_out_level(*b) + stc_depth,
                     "bootstrap: level plan differs from the one implemented");

@@ -215,11 +215,11 @@ class BootstrapPlan:
     """Device-side CKKS bootstrapping plan (include/lattisense_amd.h: lsa_bootstrap_*)."""
 
     def __init__(self, ctx, cts_depth=4, stc_depth=3, k=16, double_angle=3, message_ratio=256.0, in_scale=2.0 ** 40,
-                 out_scale=0.0, log_slots=0):
+                 out_scale=0.0, log_slots=0, sine_deg=30, arcsine_deg=0):
         self.ctx = ctx
         h = ctypes.c_void_p()
-        check(lib().lsa_bootstrap_create(ctx.h, cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale,
-                                         log_slots, ctx.stream, ctypes.byref(h)))
+        check(lib().lsa_bootstrap_create_ex(ctx.h, cts_depth, stc_depth, k, double_angle, message_ratio, in_scale, out_scale,
+                                            log_slots, sine_deg, arcsine_deg, ctx.stream, ctypes.byref(h)))
         self.h = h
         lv, sc, ng, nm, nc, sp = ctypes.c_int(), ctypes.c_double(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(lib().lsa_bootstrap_info(self.h, ctypes.byref(lv), ctypes.byref(sc), ctypes.byref(ng), ctypes.byref(nm),
@@ -236,9 +236,16 @@ class BootstrapPlan:
             self.h = None
 
     def chebyshev(self):
-        out = (ctypes.c_double * 32)()
-        check(lib().lsa_bootstrap_chebyshev(self.h, out))
-        return np.array(out[:], dtype=np.float64)
+        return self.evalmod_constants()[0]
+
+    def evalmod_constants(self):
+        """(Chebyshev coefficients of the cosine interpolant, monomial coefficients of the arcsine correction or None)"""
+        nc, na = ctypes.c_int(), ctypes.c_int()
+        check(lib().lsa_bootstrap_evalmod_constants(self.h, ctypes.byref(nc), None, ctypes.byref(na), None))
+        c = (ctypes.c_double * nc.value)()
+        a = (ctypes.c_double * max(na.value, 1))()
+        check(lib().lsa_bootstrap_evalmod_constants(self.h, None, c, None, a))
+        return np.array(c[:], dtype=np.float64), (np.array(a[: na.value], dtype=np.float64) if na.value else None)
 
     def matrix(self, index):
         """(level, n1 (0: no baby-step/giant-step), diagonal indices, {k: plaintext [level+1][N]})"""

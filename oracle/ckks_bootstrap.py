@@ -314,27 +314,83 @@ def eval_chebyshev(ev, u, coeffs):
     return rec(np.asarray(coeffs, dtype=np.float64), level_out, float(ev.q(level_out + 1)))
 
 
-def eval_mod(ev, u, K, double_angle, coeffs=None):
+def eval_monomial(ev, u, coeffs):
+    """sum_k coeffs[k] u^k, len(coeffs) a power of two: the binary splitting of eval_chebyshev in the monomial basis
+    (p = hi * u^half + lo), same exact top-down target scales"""
+    k = len(coeffs).bit_length() - 1
+    assert len(coeffs) == 1 << k and k >= 1
+    powers = {1: u}
+    for j in range(1, k):
+        p = powers[1 << (j - 1)]
+        powers[1 << j] = ev.mul(p, p)
+
+    def rec(c, level_out, scale_out):
+        if len(c) == 2:
+            t1 = ev.drop(u, level_out + 1)
+            cs = scale_out * ev.q(level_out + 1) / t1.scale
+            r = ev.rescale(ev.mul_const(t1, float(c[1]), cs))
+            r = Ct(r.data, r.level, scale_out)
+            return ev.add_const(r, float(c[0]))
+        half = len(c) // 2
+        th = ev.drop(powers[half], level_out + 1)
+        h = rec(np.array(c[half:], dtype=np.float64), level_out + 1, scale_out * ev.q(level_out + 1) / th.scale)
+        prod = ev.mul(h, th)
+        prod = Ct(prod.data, prod.level, scale_out)
+        return ev.add(prod, rec(np.array(c[:half], dtype=np.float64), level_out, scale_out))
+
+    level_out = u.level - k
+    return rec(np.asarray(coeffs, dtype=np.float64), level_out, float(ev.q(level_out + 1)))
+
+
+def arcsine_coeffs(degree):
+    """Taylor coefficients of arcsin up to the (odd) degree, padded to a power of two: sum_k C(2k,k) / (4^k (2k+1)) y^(2k+1)"""
+    n = 1
+    while n < degree + 1:
+        n *= 2
+    c = np.zeros(n)
+    binom, pow4 = 1.0, 1.0
+    k = 0
+    while 2 * k + 1 <= degree:
+        if k > 0:
+            binom = binom * (2 * k) * (2 * k - 1) / (k * k)
+            pow4 *= 4.0
+        c[2 * k + 1] = binom / (pow4 * (2 * k + 1))
+        k += 1
+    return c
+
+
+def eval_mod(ev, u, K, double_angle, coeffs=None, asin=None, sine_deg=30):
     """u = v/K with v = I + eps (I integer, |I| < K, |eps| small) -> sin(2 pi v) ~ 2 pi eps, via the Chebyshev interpolant of
-    cos(2 pi (K u - 1/4) / 2^r) on [-1, 1] (31 coefficients) and r double-angle steps y <- 2 y^2 - 1."""
+    cos(2 pi (K u - 1/4) / 2^r) on [-1, 1] (2^ceil(log2(sine_deg+1)) coefficients) and r double-angle steps y <- 2 y^2 - 1;
+    with `asin` (monomial coefficients of the arcsine series) the result is arcsin(sin(2 pi v)) = 2 pi eps beyond the sine's
+    own linear range (reference: btp_eval_mod_arcsine_deg, gpu_wrapper.cu:100-103)."""
     r = double_angle
     if coeffs is None:
-        coeffs = chebyshev_coeffs(lambda x: np.cos(2 * np.pi * (K * x - 0.25) / (1 << r)), 31)
+        m = 1
+        while m < sine_deg + 1:
+            m *= 2
+        coeffs = chebyshev_coeffs(lambda x: np.cos(2 * np.pi * (K * x - 0.25) / (1 << r)), m - 1)
     y = eval_chebyshev(ev, u, coeffs)
     for _ in range(r):
         sq = ev.mul(y, y)
         y = ev.add_const(ev.mul_int(sq, 2), -1.0)
+    if asin is not None:
+        y = eval_monomial(ev, y, asin)
     return y
 
 
 # ------------------------------------------------------------------------------------------------ bootstrap
 class Bootstrapper:
     def __init__(self, ev, cts_depth=4, stc_depth=3, K=16, double_angle=3, message_ratio=256.0, out_scale=None,
-                 plains=None, coeffs=None):
-        """plains: {("cts"|"stc", matrix index): {k: plaintext}} and coeffs (32 Chebyshev coefficients) override this
-        module's own floating-point constants with another implementation's (see linear_transform)."""
+                 plains=None, coeffs=None, sine_deg=30, arcsine_deg=0, asin=None):
+        """plains: {("cts"|"stc", matrix index): {k: plaintext}}, coeffs (Chebyshev coefficients) and asin (arcsine monomial
+        coefficients) override this module's own floating-point constants with another implementation's (see linear_transform)."""
         self.ev = ev
         self.plains, self.coeffs = plains, coeffs
+        self.sine_deg, self.arcsine_deg = sine_deg, arcsine_deg
+        self.cheb_depth = max(1, int(sine_deg).bit_length())               # ceil(log2(sine_deg + 1))
+        self.asin_depth = int(arcsine_deg).bit_length() if arcsine_deg > 0 else 0
+        self.asin = asin if asin is not None else (arcsine_coeffs(arcsine_deg) if arcsine_deg > 0 else None)
         self.n = ev.n // 2
         self.K, self.r, self.mr = K, double_angle, message_ratio
         self.cts_depth, self.stc_depth = cts_depth, stc_depth
@@ -371,7 +427,7 @@ class Bootstrapper:
             plains[("cts", i)] = encode_matrix(m, level)
             level -= 1
         u_level = level
-        level -= 5 + self.r                          # EvalMod: 32 Chebyshev coefficients (5 levels) + r double-angle steps
+        level -= self.cheb_depth + self.r + self.asin_depth   # EvalMod: cosine interpolant + r double-angle steps (+ arcsine)
         natural = self.evalmod_out_scale(u_level) * 2 * np.pi * d1 / q0
         stc = list(self.stc)
         if self.out_scale is not None:
@@ -380,7 +436,7 @@ class Bootstrapper:
         for i, m in enumerate(stc):
             plains[("stc", i)] = encode_matrix(m, level)
             level -= 1
-        coeffs = chebyshev_coeffs(lambda x: np.cos(2 * np.pi * (self.K * x - 0.25) / (1 << self.r)), 31)
+        coeffs = chebyshev_coeffs(lambda x: np.cos(2 * np.pi * (self.K * x - 0.25) / (1 << self.r)), (1 << self.cheb_depth) - 1)
         return plains, np.asarray(coeffs, dtype=np.float64), level
 
     def mod_raise(self, ct, top_level):
@@ -399,11 +455,13 @@ class Bootstrapper:
     def evalmod_out_scale(self, level_in):
         """scale bookkeeping of eval_mod without data (it does not depend on the values)"""
         ev = self.ev
-        level = level_in - 5                      # 32 Chebyshev coefficients: 5 levels
+        level = level_in - self.cheb_depth        # 2^cheb_depth Chebyshev coefficients
         s = float(ev.q(level + 1))
         for _ in range(self.r):
             s = s * s / ev.q(level)
             level -= 1
+        if self.asin_depth:
+            s = float(ev.q(level - self.asin_depth + 1))
         return s
 
     def key_switch(self, ct, key, klvl):
@@ -437,8 +495,8 @@ class Bootstrapper:
         u_re = ev.add(x, xc)                                   # Re(t)/K
         u_im = ev.mul_by_i(ev.sub(x, xc), -1)                  # Im(t)/K
         # 4. EvalMod on both halves: sin(2 pi v) ~ 2 pi d1 m_k / q0
-        y_re = eval_mod(ev, u_re, self.K, self.r, self.coeffs)
-        y_im = eval_mod(ev, u_im, self.K, self.r, self.coeffs)
+        y_re = eval_mod(ev, u_re, self.K, self.r, self.coeffs, self.asin, self.sine_deg)
+        y_im = eval_mod(ev, u_im, self.K, self.r, self.coeffs, self.asin, self.sine_deg)
         y = ev.add(y_re, ev.mul_by_i(y_im, 1))
         # 5. SlotsToCoeffs.  The slots then hold (2 pi d1 / q0) * z at scale y.scale, i.e. z at scale y.scale * 2 pi d1 / q0;
         #    a requested output scale is met by folding the ratio into the first matrix (the caller pre-sets the scale on
@@ -467,10 +525,14 @@ class SparseBootstrapper(Bootstrapper):
         (bootstrap_params.py:233, :121-133): t[k] = y[k] + i y[k+slots]."""
 
     def __init__(self, ev, log_slots, cts_depth=4, stc_depth=3, K=16, double_angle=3, message_ratio=256.0, out_scale=None,
-                 plains=None, coeffs=None):
+                 plains=None, coeffs=None, sine_deg=30, arcsine_deg=0, asin=None):
         """plains keys: ("cts", i) for the leading matrices, ("p1",), ("p2",), ("stc", i)"""
         self.ev = ev
         self.plains, self.coeffs = plains, coeffs
+        self.sine_deg, self.arcsine_deg = sine_deg, arcsine_deg
+        self.cheb_depth = max(1, int(sine_deg).bit_length())
+        self.asin_depth = int(arcsine_deg).bit_length() if arcsine_deg > 0 else 0
+        self.asin = asin if asin is not None else (arcsine_coeffs(arcsine_deg) if arcsine_deg > 0 else None)
         self.n = ev.n // 2
         self.ns = ns = 1 << log_slots
         self.log_slots = log_slots
@@ -536,7 +598,7 @@ class SparseBootstrapper(Bootstrapper):
         a = linear_transform(ev, x, self.p1, rescale=False, n_slots=2 * ns, plains=pl.get(("p1",)))
         b = linear_transform(ev, ev.conj(x), self.p2, rescale=False, n_slots=2 * ns, plains=pl.get(("p2",)))
         u = ev.rescale(ev.add(a, b))                                    # [Re(t)/K | Im(t)/K], period 2*slots
-        y = eval_mod(ev, u, self.K, self.r, self.coeffs)
+        y = eval_mod(ev, u, self.K, self.r, self.coeffs, self.asin, self.sine_deg)
         natural = y.scale * 2 * np.pi * d1 / q0
         stc = list(self.stc)
         if self.out_scale is not None:

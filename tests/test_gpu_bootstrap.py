@@ -290,3 +290,54 @@ def test_bootstrap_reference_parameter_set_full_size():
     print("N=2^16 bootstrap: level 0 -> %d, mean precision %.1f / %.1f bits" % (plan.out_level, re, im))
     assert re >= 10 and im >= 10
     plan.close()
+
+
+@pytest.mark.parametrize("sine_deg,arcsine_deg", [(63, 0), (30, 7), (63, 7)])
+def test_wider_evalmod_configurations(sine_deg, arcsine_deg):
+    """EvalMod configurations the reference forwards besides its default (gpu_wrapper.cu:100-103: btp_eval_mod_sine_deg,
+    btp_eval_mod_arcsine_deg): a degree-63 cosine interpolant (6 levels) and the arcsine correction (degree 7: 3 more levels), on a
+    chain with enough 60-bit EvalMod primes.  Device == oracle program bit for bit (fed the device plan's constants), the
+    device's arcsine coefficients == the oracle's own Taylor coefficients, and the reference's precision bar (>= 10 bits)."""
+    need_gpu()
+    from lattisense_amd import params
+    from lattisense_amd.device import ALGO_CKKS, BootstrapPlan, DeviceContext
+    from oracle.ckks_bootstrap import Bootstrapper, Ct, Evaluator, arcsine_coeffs
+    from oracle.client import Client, mean_precision_bits
+    from oracle.pyoracle import Oracle
+    N = 1 << 10
+    B = params.CKKS_BOOTSTRAP_65536
+    depth = (6 if sine_deg > 31 else 5) + 3 + (3 if arcsine_deg else 0)
+    # the reference chain's shape (custom_task.py:387-420) with `depth` EvalMod primes instead of 8: q0, output levels, StC, sine, CtS
+    sine = params.ntt_primes_below(60, 1 << 16, depth + 4, avoid=B["q"])[4:]
+    q = B["q"][:13] + sine + B["q"][21:]
+    o = Oracle(N, q, B["p"], 0)
+    c = Client(o, seed=77 + sine_deg + arcsine_deg, hamming=32)
+    ctx = DeviceContext(ALGO_CKKS, N, q, B["p"])
+    top = len(q) - 1
+    D = float(2 ** 40)
+    plan = BootstrapPlan(ctx, in_scale=D, out_scale=D, sine_deg=sine_deg, arcsine_deg=arcsine_deg)
+    assert plan.out_level == 9
+    cheb, asin = plan.evalmod_constants()
+    assert len(cheb) == (64 if sine_deg > 31 else 32)
+    if arcsine_deg:
+        assert np.allclose(asin, arcsine_coeffs(arcsine_deg), rtol=1e-15, atol=0)
+        assert abs(asin[1] - 1.0) < 1e-15 and abs(asin[3] - 1.0 / 6) < 1e-15 and abs(asin[5] - 3.0 / 40) < 1e-15
+    else:
+        assert asin is None
+    ev = Evaluator(o, c, top)
+    rlk = ctx.upload_key(ev.rlk, top)
+    keys = {e: c.gen_galois_key(e, top) for e in plan.galois_elements}
+    ev.glk = dict(keys)
+    glk = {e: ctx.upload_key(k, top) for e, k in keys.items()}
+    rng = np.random.default_rng(sine_deg)
+    z = rng.uniform(-1, 1, N // 2) + 1j * rng.uniform(-1, 1, N // 2)
+    cts = np.stack([c.ckks_encrypt(z, 0, D)])
+    out = plan.run(ctx.upload(cts), 1, rlk, glk)
+    got = ctx.download(out, (1, 2, plan.out_level + 1, N))
+    bt = Bootstrapper(ev, out_scale=D, plains=plan.oracle_plains(), coeffs=cheb, sine_deg=sine_deg, arcsine_deg=arcsine_deg, asin=asin)
+    want = bt.bootstrap(Ct(cts[0], 0, D), top)
+    assert want.level == plan.out_level and want.scale == D
+    assert np.array_equal(got[0], want.data)
+    re, im = mean_precision_bits(z, c.ckks_decrypt(got[0], D))
+    assert re >= 10 and im >= 10, (re, im)
+    plan.close()
