@@ -32,6 +32,7 @@ struct lsa_context_st {
 };
 struct lsa_key_st {
     Key key;
+    double* fp_owned = nullptr;   // the double copy of an adopted key (the caller's buffer has no room for it)
 };
 
 template <typename F>
@@ -184,15 +185,7 @@ size_t lsa_key_bytes(lsa_context ctx, int key_level) {
     return beta * 2 * (size_t)(key_level + 1 + c.np) * c.n * sizeof(u64);
 }
 
-static void key_to_mont(Context& c, Key& k, hipStream_t s) {
-    const int comp = k.level + 1 + c.np;
-    const int beta = (k.level + 1 + c.np - 1) / c.np;
-    RowMap rm;
-    rm.period = comp;
-    LSA_REQUIRE(comp <= LSA_MAX_PERIOD, "key has too many limbs");
-    for (int j = 0; j < comp; j++) rm.mod_of[j] = (unsigned char)(j <= k.level ? j : c.p_mod(j - k.level - 1));
-    launch_to_mont(c, k.data, beta * 2 * comp, rm, s);
-}
+struct lsa_key_fp_owner;   // (see lsa_key_st::fp_owned)
 
 int lsa_key_upload(lsa_context ctx, const uint64_t* compact_host, int key_level, void* stream, lsa_key* out) {
     return guard([&] {
@@ -203,9 +196,12 @@ int lsa_key_upload(lsa_context ctx, const uint64_t* compact_host, int key_level,
         auto k = std::make_unique<lsa_key_st>();
         k->key.level = key_level;
         k->key.owned = true;
-        LSA_HIP(hipMalloc((void**)&k->key.data, bytes));
+        const bool with_fp = ks_fused_enabled(c);   // the double copy sits behind the key in the same allocation
+        LSA_HIP(hipMalloc((void**)&k->key.data, with_fp ? 2 * bytes : bytes));
         LSA_HIP(hipMemcpyAsync(k->key.data, compact_host, bytes, hipMemcpyHostToDevice, S(stream)));
-        key_to_mont(c, k->key, S(stream));
+        double* fp = with_fp ? reinterpret_cast<double*>(k->key.data + bytes / sizeof(u64)) : nullptr;
+        launch_key_prepare(c, k->key.data, fp, key_level, S(stream));
+        k->key.fp = fp;
         LSA_HIP(hipStreamSynchronize(S(stream)));  // host buffer may be released by the caller on return
         *out = k.release();
     });
@@ -214,12 +210,17 @@ int lsa_key_adopt_device(lsa_context ctx, uint64_t* compact_dev, int key_level, 
     return guard([&] {
         Context& c = C(ctx);
         LSA_REQUIRE(out != nullptr && compact_dev != nullptr, "null argument");
-        LSA_REQUIRE(lsa_key_bytes(ctx, key_level) > 0, "bad key level (or context has no special primes)");
+        const size_t bytes = lsa_key_bytes(ctx, key_level);
+        LSA_REQUIRE(bytes > 0, "bad key level (or context has no special primes)");
         auto k = std::make_unique<lsa_key_st>();
         k->key.level = key_level;
         k->key.owned = false;
         k->key.data = compact_dev;
-        key_to_mont(c, k->key, S(stream));
+        if (ks_fused_enabled(c)) {   // the caller's buffer has no room: the double copy is this handle's own allocation
+            LSA_HIP(hipMalloc((void**)&k->fp_owned, bytes));
+            k->key.fp = k->fp_owned;
+        }
+        launch_key_prepare(c, k->key.data, k->fp_owned, key_level, S(stream));
         *out = k.release();
     });
 }
@@ -228,6 +229,7 @@ int lsa_key_destroy(lsa_context ctx, lsa_key key) {
         C(ctx);
         if (key) {
             if (key->key.owned && key->key.data) LSA_HIP(hipFree(key->key.data));
+            if (key->fp_owned) LSA_HIP(hipFree(key->fp_owned));
             delete key;
         }
     });

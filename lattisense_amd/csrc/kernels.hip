@@ -188,6 +188,157 @@ static bool ntt_launch_r16(const NttPassArgs& a, int npass, bool fused, long lon
     return true;
 }
 
+// ---- second pass of the extension transform + key MAC in one launch (ntt_r16.h, "second pass + key MAC")
+// grid: (tile, tl, b) with b fastest: consecutive workgroups are consecutive ciphertexts at one (limb, tile) -- they read the
+// same key tile within microseconds of each other -- and a CU's resident workgroups mix integer- and FP64-engine limbs
+#ifndef LSA_KSMAC_WAVES
+#define LSA_KSMAC_WAVES 2   // 32 running sums (64 VGPRs) stay live across the transform phases: at 3 workgroups per CU (168 VGPRs) 76 registers spill
+#endif
+#ifndef LSA_KSMAC_WAVES_FP
+#define LSA_KSMAC_WAVES_FP LSA_KSMAC_WAVES
+#endif
+template <int MU, bool FP>
+__global__ __launch_bounds__(LSA_R16_THREADS, FP ? LSA_KSMAC_WAVES_FP : LSA_KSMAC_WAVES) void k_ntt_r16_ksmac(KsFusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const int T = g.L + g.np;
+    long long bid = blockIdx.x;
+    const long long b = bid % g.batch;
+    bid /= g.batch;
+    const int tl = g.tl_list[bid % g.n_tl], tile = (int)(bid / g.n_tl);
+    NttPassArgs a;   // only the scalar fields the pass functions read are set (the row tables are never indexed here)
+    a.logn = g.logn;
+    a.s_lo = g.logn - MU;
+    a.mu = MU;
+    a.lambda = 0;
+    a.tau = 12;
+    a.inverse = 0;
+    a.apply_scale = 0;
+    a.final_reduce = 1;
+    a.fp_raw_in = g.fp_raw_in;
+    a.fp_raw_out = 0;
+    a.mods = g.mods;
+    a.tw = g.tw;
+    a.twd = g.twd;
+    a.scale = nullptr;
+    a.scaled = nullptr;
+    a.src = g.ext;
+    a.fz_pro = a.fz_epi = 0;
+    NttBlockCtx bc;
+    bc.tile = tile;
+    bc.mod = tl < g.L ? tl : g.nq + (tl - g.L);
+    bc.fp = FP;   // (the launcher put this limb on the launch of its engine)
+    bc.b = (int)b;
+    bc.row = 0;
+    bc.tw_l = nullptr;
+    bc.base_dst = 0;
+    const R16Limb L = r16_limb(a, bc);
+    const int kj = tl < g.L ? tl : g.klvl + 1 + (tl - g.L);
+    const int own_d = tl < g.L ? tl / g.np : -1;
+    int k, i;
+    r16_lane<1, MU>(tid, k, i);
+    const unsigned G1 = r16_G1<1, MU>(bc, k), G2 = (G1 << 4) + ((unsigned)i << (8 - MU));
+    u64 acc0[16], acc1[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc0[e] = acc1[e] = 0;   // (0 is also +0.0)
+    for (int d = 0; d < g.beta; d++) {
+        const bool own = d == own_d;
+        if (!own) {
+            bc.base_src = b * g.sext + ((long long)(d * T + tl) << g.logn);
+            bc.row = d * T + tl;
+            u64 v[16];
+            r16_load_direct<1, false, 0, MU>(a, bc, tid, v);
+            r16_group<1, 0, MU>(v, a, bc, L, G1);
+            r16_lds_put<1, 0, MU>(tid, lds, v);
+            r16_sync<1>();
+            r16_lds_get<1, 1, MU>(tid, lds, v);
+            r16_group<1, 1, MU>(v, a, bc, L, G2);
+            r16_lds_put<1, 1, MU>(tid, lds, v);
+            r16_sync<1>();
+        }
+        r16_mac_digit<MU, FP>(g, a, bc, L, tid, d, kj, own, b, tl, lds, acc0, acc1);
+        r16_sync<1>();   // the next digit's first exchange overwrites the tile image these lanes just read
+    }
+    r16_mac_store<MU, FP>(g, a, bc, L, tid, b, tl, acc0, acc1);
+}
+
+bool ks_fused_enabled(const Context& c) {
+    static const bool on = [] {
+        const char* e = getenv("LSA_KS_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (!on || c.plan.npass != 2 || !c.fp_raw) return false;
+    const NttPassShape& p = c.plan.pass[1];
+    return p.tau == 12 && p.lambda == 0 && (p.mu == 7 || p.mu == 8) && p.s_lo == c.logn - p.mu;
+}
+
+int ks_fused_engines(const Context& c) {
+    // integer-engine target limbs measured slower fused than apart (two lazy REDCs per product and digit, 256 VGPRs and still
+    // spilling: 593 us against ~500 for pass + MAC on the headline's 5 integer limbs), FP64-engine limbs faster (643 us for 36
+    // transforms + their MAC against ~1050): profiles/r03/ab_ks_fused_kernel_stats.log
+    static const int e = [] {
+        const char* v = getenv("LSA_KS_FUSED_ENGINES");
+        return v ? atoi(v) & 3 : 2;
+    }();
+    return c.fp64_ntt ? e : 0;
+}
+
+bool launch_ntt_ksmac(Context& c, int level, const u64* cx, long long scx, u64* ext, long long sext, const Key& key, u64* acc,
+                      long long sacc, int batch, hipStream_t s, int engines) {
+    if (batch <= 0) return true;
+    if (!ks_fused_enabled(c) || (c.fp64_ntt && !key.fp)) return false;
+    LSA_REQUIRE(key.level >= level, "key-switch key exported at a lower level than the ciphertext");
+    KsFusedArgs g{};
+    g.ext = ext;
+    g.cx = cx;
+    g.key = key.data;
+    g.keyd = key.fp;
+    g.acc = acc;
+    g.sext = sext;
+    g.scx = scx;
+    g.sacc = sacc;
+    g.mods = c.d_mods;
+    g.tw = c.d_psi;
+    g.twd = c.d_psi_d;
+    g.logn = c.logn;
+    g.L = level + 1;
+    g.np = c.np;
+    g.nq = c.nq;
+    g.beta = (g.L + c.np - 1) / c.np;
+    g.klvl = key.level;
+    g.kcomp = key.level + 1 + c.np;
+    g.batch = batch;
+    g.allow_fp64 = c.fp64_ntt;
+    g.fp_raw_in = c.fp_raw;
+    const int T = g.L + c.np, mu = c.plan.pass[1].mu;
+    LSA_REQUIRE(T <= 64, "fused key MAC: too many target limbs");
+    const size_t lds_bytes = (size_t)LSA_R16_LDS_WORDS * sizeof(u64);
+    // one launch per butterfly engine (own register budget each); bytes: one pass of the launch's extension transforms
+    // (16 N / 2 per limb) + its share of the gadget inner product as launch_ks_mac counts it
+    for (int eng = 0; eng < 2; eng++) {
+        g.n_tl = 0;
+        int transforms = 0;
+        for (int tl = 0; tl < T; tl++) {
+            const int mi = tl < g.L ? tl : c.p_mod(tl - g.L);
+            const bool fp = c.fp64_ntt && (c.T.mod[mi] >> LSA_FP64_MAX_BITS) == 0;
+            if ((int)fp != eng || !((engines >> eng) & 1)) continue;
+            g.tl_list[g.n_tl++] = (unsigned char)tl;
+            transforms += g.beta - (tl < g.L ? 1 : 0);
+        }
+        if (!g.n_tl) continue;
+        const long long nblocks = (long long)batch * g.n_tl * (1 << (c.logn - 12));
+        LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
+        ProfScope ps(c, PROF_NTT, 16.0 * c.n * transforms * batch / 2 + 8.0 * c.n * g.n_tl * (batch * ((double)g.beta + 2.0) + 2.0 * g.beta), s);
+        const dim3 grid((unsigned)nblocks), block(LSA_R16_THREADS);
+        if (mu == 8 && eng) hipLaunchKernelGGL((k_ntt_r16_ksmac<8, true>), grid, block, lds_bytes, s, g);
+        else if (mu == 8) hipLaunchKernelGGL((k_ntt_r16_ksmac<8, false>), grid, block, lds_bytes, s, g);
+        else if (eng) hipLaunchKernelGGL((k_ntt_r16_ksmac<7, true>), grid, block, lds_bytes, s, g);
+        else hipLaunchKernelGGL((k_ntt_r16_ksmac<7, false>), grid, block, lds_bytes, s, g);
+    }
+    LSA_HIP(hipGetLastError());
+    return true;
+}
+
 template <int FZ, int NT>
 static void ntt_launch_variant(const NttPassArgs& a, long long nblocks, size_t lds_bytes, hipStream_t s) {
     if (lds_bytes > 65536) {   // whole-limb tiles: opt in to more than 64 KiB of dynamic LDS, once per kernel instance AND device
@@ -224,7 +375,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long batch
 }
 
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
-                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz) {
+                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz, int passes) {
     if (batch <= 0 || rows <= 0) return;
     LSA_REQUIRE(rm.period >= 1 && rm.period <= LSA_MAX_PERIOD, "ntt: bad row-map period");
     NttPassArgs a{};
@@ -296,6 +447,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         const long long limbs = (long long)active_rows * batch;
         wide = !fz && (c.logn == 13 ? limbs >= 1024 : (all_fp && limbs >= 512));
     }
+    if (passes != 3) wide = false;   // a caller that runs the passes separately means the two-pass plan
     const NttPlan& plan = wide ? c.plan_wide : c.plan;
     a.tw = wide ? (inverse ? c.d_psiinv_w : c.d_psi_w) : (inverse ? c.d_psiinv : c.d_psi);
     a.twd = wide ? (inverse ? c.d_psiinv_d_w : c.d_psi_d_w) : (inverse ? c.d_psiinv_d : c.d_psi_d);
@@ -319,6 +471,7 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         const int nb = std::min(chunk, batch - b0);
         a.batch = nb;
         for (int step = 0; step < plan.npass; step++) {
+            if (plan.npass == 2 && !((passes >> step) & 1)) continue;
             const int k = inverse ? plan.npass - 1 - step : step;
             ntt_fill_pass(a, plan, c.logn, k, inverse ? 1 : 0);
             a.fp_raw_out = plan.npass == 2 && step == 0 && c.fp_raw;
@@ -935,6 +1088,8 @@ struct KsMacArgs {
     long long scx, sext, sacc;
     const ModDev* mods;
     int logn, L, np, nq, beta, kcomp, klvl, batch, bpt;
+    int n_tl;                      // 0: every target limb; else the launch covers tl_list[0..n_tl)
+    unsigned char tl_list[64];
 };
 
 // grid: x = T * (N/2/TPB), y = groups of `bpt` batch items.  The key is in Montgomery form, so sum_d ext_d*key_d needs
@@ -944,7 +1099,7 @@ struct KsMacArgs {
 template <int KB>
 __global__ __launch_bounds__(TPB) void k_ks_mac(KsMacArgs g) {
     const int chunks = (1 << g.logn) / (2 * TPB);
-    const int tl = blockIdx.x / chunks;
+    const int tl = g.n_tl ? g.tl_list[blockIdx.x / chunks] : blockIdx.x / chunks;
     const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
     const int T = g.L + g.np;
     const int mi = tl < g.L ? tl : g.nq + (tl - g.L);
@@ -1040,7 +1195,7 @@ __global__ __launch_bounds__(TPB) void k_ks_mac(KsMacArgs g) {
 }
 
 void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext, const Key& key,
-                   u64* acc, long long sacc, int batch, hipStream_t s) {
+                   u64* acc, long long sacc, int batch, hipStream_t s, int engine) {
     if (batch <= 0) return;
     KsMacArgs g{};
     g.cx = cx;
@@ -1059,10 +1214,21 @@ void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u6
     g.klvl = key.level;
     g.kcomp = key.level + 1 + c.np;
     LSA_REQUIRE(key.level >= level, "key-switch key exported at a lower level than the ciphertext");
-    const double T = g.L + c.np;
+    int targets = g.L + c.np;
+    if (engine >= 0) {   // only the target limbs of one butterfly engine (the others went through the fused kernel)
+        LSA_REQUIRE(targets <= 64, "key MAC: too many target limbs for a subset launch");
+        for (int tl = 0; tl < targets; tl++) {
+            const int mi = tl < g.L ? tl : c.p_mod(tl - g.L);
+            const bool fp = c.fp64_ntt && (c.T.mod[mi] >> LSA_FP64_MAX_BITS) == 0;
+            if ((int)fp == engine) g.tl_list[g.n_tl++] = (unsigned char)tl;
+        }
+        if (!g.n_tl) return;
+        targets = g.n_tl;
+    }
+    const double T = targets;
     ProfScope ps(c, PROF_KSMAC, 8.0 * c.n * (batch * (g.beta * T + 2 * T) + 2.0 * g.beta * T), s);
     // enough workgroups to fill the chip, as few key re-reads as possible
-    const dim3 grid1 = ew_grid(c, g.L + c.np, 1);
+    const dim3 grid1 = ew_grid(c, targets, 1);
     const int groups = std::max(1, std::min(batch, (int)((2048 + grid1.x - 1) / grid1.x)));
     g.batch = batch;
     g.bpt = (batch + groups - 1) / groups;
@@ -1362,6 +1528,46 @@ void launch_to_mont(Context& c, u64* data, int rows, const RowMap& rm, hipStream
     g.logn = c.logn;
     fill_rowmap(g.mod_of, g.period, rm, c.nmod);
     hipLaunchKernelGGL(k_to_mont, ew_grid(c, rows, 1), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// a freshly loaded key: plain residues -> Montgomery form in place, and (fp != null) the same values as doubles for the limbs
+// the FP64 engine serves
+struct KeyPrepArgs {
+    u64* data;
+    double* fp;
+    const ModDev* mods;
+    int logn, period, allow_fp64;
+    unsigned char mod_of[LSA_MAX_PERIOD];
+};
+__global__ __launch_bounds__(TPB) void k_key_prepare(KeyPrepArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const ModDev m = g.mods[g.mod_of[row % g.period]];
+    const long long off = ((long long)row << g.logn) + x;
+    const ulonglong2 v = ld2(g.data + off);
+    st2(g.data + off, mont_mul(v.x, m.r2, m.q, m.qinv), mont_mul(v.y, m.r2, m.q, m.qinv));
+    if (g.fp) {
+        const bool fp = g.allow_fp64 && (m.q >> LSA_FP64_MAX_BITS) == 0;
+        double2 d;
+        d.x = fp ? (double)v.x : 0.0;
+        d.y = fp ? (double)v.y : 0.0;
+        *reinterpret_cast<double2*>(g.fp + off) = d;
+    }
+}
+void launch_key_prepare(Context& c, u64* data, double* fp, int key_level, hipStream_t s) {
+    const int comp = key_level + 1 + c.np, beta = (key_level + 1 + c.np - 1) / c.np;
+    LSA_REQUIRE(comp <= LSA_MAX_PERIOD, "key has too many limbs");
+    KeyPrepArgs g{};
+    g.data = data;
+    g.fp = fp;
+    g.mods = c.d_mods;
+    g.logn = c.logn;
+    g.period = comp;
+    g.allow_fp64 = c.fp64_ntt;
+    for (int j = 0; j < comp; j++) g.mod_of[j] = (unsigned char)(j <= key_level ? j : c.p_mod(j - key_level - 1));
+    hipLaunchKernelGGL(k_key_prepare, ew_grid(c, beta * 2 * comp, 1), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
 

@@ -74,6 +74,10 @@ struct Key {
     u64* data = nullptr;   // device, compact order [beta][2][klvl+1+np][N], NTT domain, MONTGOMERY form
     int level = 0;
     bool owned = true;
+    // the same key as plain integer-valued doubles, same layout, valid for the limbs of the FP64 engine (q < 2^47) only: the
+    // operand of the key MAC that is fused into the extension transform's second pass (k_ntt_r16_ksmac); null = not built
+    // (that path is then not taken).  Lives and dies with `data` (same allocation, or owned by the key's holder).
+    const double* fp = nullptr;
 };
 
 struct Context {
@@ -213,8 +217,10 @@ struct NttFusion {
     int last_rpp = 1;            // rows between the polynomials' last limbs in `last`
     const u64* k2 = nullptr;     // epi == 2: out = (a*k - v + base) * k2
 };
+// passes: bit 0 = the first executed pass, bit 1 = the second (two-pass plans; a caller that fuses the second pass into
+// another kernel asks for 1 only)
 void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_stride, long long dst_stride, int rows,
-                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz = nullptr);
+                const RowMap& rm, bool inverse, hipStream_t s, const NttFusion* fz = nullptr, int passes = 3);
 
 // limb-wise binary/unary ops on [batch][rows][N]; row r uses modulus rm.mod_of[r % period]
 enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MUL = 3 };
@@ -244,8 +250,9 @@ struct BaseConvRows {
 void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
                      long long ssrc, long long sdst, hipStream_t s);
 // key-switch inner product: acc[h][tl] = sum_d ext(d,tl) * key[d][h][tl];  ext(d,tl) = cx[tl] when tl is in digit d
+// engine: -1 every target limb; 0 / 1 only the target limbs of the integer / FP64 butterfly engine
 void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext,
-                   const Key& key, u64* acc, long long sacc, int batch, hipStream_t s);
+                   const Key& key, u64* acc, long long sacc, int batch, hipStream_t s, int engine = -1);
 // out[h][i] = base[h][i] + (acc[h][i] - conv[h][i]) * Pinv_i       (base may be null)
 void launch_moddown_final(Context& c, int level, const u64* acc, long long sacc, int acc_rows_per_poly, const u64* conv,
                           long long sconv, const u64* base, long long sbase, int base_rows_per_poly, int base_polys,
@@ -269,6 +276,14 @@ void launch_permute_coeff(Context& c, const u32* perm, const u64* in, long long 
 void launch_copy_rows(Context& c, const u64* in, long long sin, u64* out, long long sout, int rows, const int* src_row,
                       int batch, hipStream_t s);
 void launch_to_mont(Context& c, u64* data, int rows, const RowMap& rm, hipStream_t s);
+// a freshly loaded key (plain residues, compact order) -> Montgomery form in place (+ the double copy when fp != nullptr)
+void launch_key_prepare(Context& c, u64* data, double* fp, int key_level, hipStream_t s);
+bool ks_fused_enabled(const Context& c);   // the fused second-pass + key-MAC kernel applies to this context (and is not switched off)
+// second pass of the extension transform + gadget inner product in one launch (see k_ntt_r16_ksmac); false = shape not covered
+// engines: bit 0 integer-engine target limbs, bit 1 FP64-engine target limbs
+bool launch_ntt_ksmac(Context& c, int level, const u64* cx, long long scx, u64* ext, long long sext, const Key& key, u64* acc,
+                      long long sacc, int batch, hipStream_t s, int engines = 3);
+int ks_fused_engines(const Context& c);   // which engines' target limbs take the fused kernel (LSA_KS_FUSED_ENGINES, default FP64 only)
 // out = (a - b) * k_i  with per-row constant (Montgomery form) ; out = a * k_i
 void launch_sub_mul_const(Context& c, const u64* a, long long sa, const u64* b, long long sb, const u64* kvec, u64* out,
                           long long so, int rows, const RowMap& rm, int batch, hipStream_t s);

@@ -396,3 +396,122 @@ LSA_HD void r16_phase(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64*
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------- second pass + key MAC
+// The extension transform's second pass fused with the gadget inner product of a key switch (SURVEY K1 + K7): one workgroup
+// owns (ciphertext b, target limb tl, tile) and walks the beta digits -- for every digit but the one that contains tl it runs
+// the pass on that digit's extended limb (pass-one output in `ext`) exactly as k_ntt_r16<1, 0, MU> does, the limb's own digit
+// reads the ciphertext's NTT-domain limb as it is -- and instead of storing the transformed tile it multiplies it with the key's
+// two polynomials at the same positions and keeps the sums in registers (the coalesced 16-byte-pair image of the tile, the one
+// the plain pass stores from).  The transformed extension (55 of the headline's 727 limb streams per ciphertext) is never
+// written, the stand-alone MAC (its 68 reads) never runs; the key tile is re-read per ciphertext from L2 / Infinity Cache
+// (consecutive workgroups are consecutive ciphertexts at one (tl, tile): the 64 of a tile share it).
+// FP64-engine limbs multiply with the key's double copy (Key::fp): 7 double operations per product-and-add; integer limbs with
+// the Montgomery-form key (one lazy REDC per product).  Same canonical residues as launch_ks_mac: the sums are sums mod q.
+struct KsFusedArgs {
+    const u64* ext;   // [batch][beta * T][N]: pass-one output of the extension transform (own-digit rows unused)
+    const u64* cx;    // [batch][L][N]: the switched polynomial, NTT domain (the digits' own limbs)
+    const u64* key;   // Montgomery form, compact [beta][2][kcomp][N]
+    const double* keyd;
+    u64* acc;         // [batch][2][T][N]
+    long long sext, scx, sacc;
+    const ModDev* mods;
+    const u64* tw;
+    const double* twd;
+    int logn, L, np, nq, beta, kcomp, klvl, batch, allow_fp64, fp_raw_in;
+    int n_tl;                      // target limbs of this launch (one launch per butterfly engine: each has its own register budget)
+    unsigned char tl_list[64];
+};
+
+// the MAC of one digit on the pair image: vin = the operand pair values (FP: doubles' bits), acc0/acc1 the two halves' sums
+template <int MU, bool FP>
+LSA_HD void r16_mac_digit(const KsFusedArgs& g, const NttPassArgs& a, const NttBlockCtx& bc, const R16Limb& L, int tid, int d, int kj,
+                          bool own, long long b, int tl, const u64* lds, u64 (&acc0)[16], u64 (&acc1)[16]) {
+    const long long N = 1LL << g.logn;
+    const u64* k0 = g.key + ((long long)(2 * d) * g.kcomp + kj) * N;
+    const u64* k1 = k0 + (long long)g.kcomp * N;
+    const double* k0d = g.keyd + ((long long)(2 * d) * g.kcomp + kj) * N;
+    const double* k1d = k0d + (long long)g.kcomp * N;
+    const u64* own_src = g.cx + b * g.scx + (long long)tl * N;
+    const u64 q = L.md.q, qinv = L.md.qinv;
+    const bool lazy = ntt_int_lazy(q);
+    const u64 one_s = L.tw[1];   // floor(2^64 / q): the Shoup quotient of 1 (entry 0 of the limb's table)
+#ifndef LSA_KSMAC_CHUNK
+#define LSA_KSMAC_CHUNK 4   // 16-byte pairs whose operand and key loads are in flight together
+#endif
+    constexpr int CH = LSA_KSMAC_CHUNK;
+#pragma unroll
+    for (int m0 = 0; m0 < 8; m0 += CH) {
+        u64 v[2 * CH], ka[2 * CH], kb[2 * CH];
+        long long xs[CH];
+#pragma unroll
+        for (int m = 0; m < CH; m++) {
+            int k, i;
+            r16_pair_pos<MU>(tid, m0 + m, k, i);
+            xs[m] = r16_x<1, MU>(a, bc.tile, k, i);
+            if (own) {
+                ntt_load_data_pair(own_src + xs[m], v[2 * m], v[2 * m + 1]);
+            } else {
+                v[2 * m] = lds[r16_lds<1, MU>(k, i)];
+                v[2 * m + 1] = lds[r16_lds<1, MU>(k, i + 1)];
+            }
+            if (FP) {
+                ntt_load_pair(reinterpret_cast<const u64*>(k0d + xs[m]), ka[2 * m], ka[2 * m + 1]);
+                ntt_load_pair(reinterpret_cast<const u64*>(k1d + xs[m]), kb[2 * m], kb[2 * m + 1]);
+            } else {
+                ntt_load_pair(k0 + xs[m], ka[2 * m], ka[2 * m + 1]);
+                ntt_load_pair(k1 + xs[m], kb[2 * m], kb[2 * m + 1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * CH; j++) {
+            const int e = 2 * m0 + j;
+            if (FP) {
+                // the transformed value is an integer-valued double of magnitude < 11 q (unreduced forward pass), the own limb a
+                // canonical residue: both within fp_modmul's operand range
+                const double x = own ? u52_to_double(v[j]) : d_from_bits(v[j]);
+                acc0[e] = d_to_bits(d_from_bits(acc0[e]) + fp_modmul(x, d_from_bits(ka[j]), L.q, L.qinv));
+                acc1[e] = d_to_bits(d_from_bits(acc1[e]) + fp_modmul(x, d_from_bits(kb[j]), L.q, L.qinv));
+            } else {
+                u64 x = v[j];
+                if (!own) {   // unreduced transform output -> below 4q (lazy limbs: anything below 2^64; others: below 8q)
+#if !defined(LSA_NTT_EXACT_BFLY)
+                    x = lazy ? shoup_mul_approx(x, 1, one_s, 0 - q) : csub_sign(x, 0 - 4 * q);
+#else
+                    x = csub(x, 2 * q);
+#endif
+                }
+                // key in Montgomery form: x * k * R^-1 in [0, 2q); the running sums stay below 2q
+                acc0[e] = csub_sign(acc0[e] + mont_mul_lazy(x, ka[j], q, qinv), 0 - 2 * q);
+                acc1[e] = csub_sign(acc1[e] + mont_mul_lazy(x, kb[j], q, qinv), 0 - 2 * q);
+            }
+        }
+    }
+}
+template <int MU, bool FP>
+LSA_HD void r16_mac_store(const KsFusedArgs& g, const NttPassArgs& a, const NttBlockCtx& bc, const R16Limb& L, int tid, long long b, int tl,
+                          const u64 (&acc0)[16], const u64 (&acc1)[16]) {
+    const long long N = 1LL << g.logn;
+    const int T = g.L + g.np;
+    u64* o0 = g.acc + b * g.sacc + (long long)tl * N;
+    u64* o1 = o0 + (long long)T * N;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        int k, i;
+        r16_pair_pos<MU>(tid, m, k, i);
+        const long long x = r16_x<1, MU>(a, bc.tile, k, i);
+        u64 r[4] = {acc0[2 * m], acc0[2 * m + 1], acc1[2 * m], acc1[2 * m + 1]};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (FP) {
+                double t = fp_reduce(d_from_bits(r[j]), L.q, L.qinv);
+                if (t < 0) t += L.q;
+                r[j] = double_to_u52(t);
+            } else {
+                r[j] = csub(r[j], L.md.q);
+            }
+        }
+        ntt_store_pair(o0 + x, r[0], r[1]);
+        ntt_store_pair(o1 + x, r[2], r[3]);
+    }
+}

@@ -42,13 +42,14 @@ struct KsRescale {
 // With `rs` (needs fused tails): p is scratch of the same shape and rs->out receives rescale(p).
 static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
-                      const KsRescale* rs, bool coeff_out = false);
+                      const KsRescale* rs, bool coeff_out = false, bool ext_first_pass_only = false);
 
 // steps 1-3: cx out of the NTT domain, every digit converted to the other limbs of Q u P, extended limbs back into the
 // NTT domain (workspace layout: cxi | ext | acc | conv).  cx_coef: the same polynomial in the coefficient domain if the
 // caller has it (BFV): the inverse transform is skipped.
+// second_pass = false: the extended limbs are left in first-pass form for the fused second pass + key MAC (ks_finish)
 static void ks_decompose(Context& c, int level, const u64* cx, long long scx, int nb, u64* ws, hipStream_t s,
-                         const u64* cx_coef = nullptr, long long s_coef = 0) {
+                         const u64* cx_coef = nullptr, long long s_coef = 0, bool second_pass = true) {
     LSA_REQUIRE(c.np >= 1, "key switching needs at least one special prime");
     LSA_REQUIRE(level >= 0 && level < c.nq, "level out of range");
     const long long N = c.n;
@@ -92,7 +93,19 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
                 const bool own = tl >= d * np && tl < std::min((d + 1) * np, L);
                 rm.mod_of[d * T + tl] = own ? LSA_ROW_SKIP : (unsigned char)tl_mod(tl);
             }
-        launch_ntt(c, ext, ext, nb, s_ext, beta * T, rm, false, s);
+        launch_ntt(c, ext, ext, nb, s_ext, s_ext, beta * T, rm, false, s, nullptr, second_pass ? 3 : 1);
+        if (!second_pass && ks_fused_engines(c) != 3) {
+            // the target limbs whose engine does not take the fused kernel get their second pass here (stand-alone MAC later)
+            RowMap r2 = rm;
+            bool any = false;
+            for (int i = 0; i < beta * T; i++) {
+                if (r2.mod_of[i] == LSA_ROW_SKIP) continue;
+                const bool fp = c.fp64_ntt && (c.T.mod[r2.mod_of[i]] >> LSA_FP64_MAX_BITS) == 0;
+                if ((ks_fused_engines(c) >> (fp ? 1 : 0)) & 1) r2.mod_of[i] = LSA_ROW_SKIP;
+                else any = true;
+            }
+            if (any) launch_ntt(c, ext, ext, nb, s_ext, s_ext, beta * T, r2, false, s, nullptr, 2);
+        }
     } else {
         for (int d = 0; d < beta; d++) {
             RowMap rm;
@@ -101,7 +114,7 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
                 const bool own = tl >= d * np && tl < std::min((d + 1) * np, L);
                 rm.mod_of[tl] = own ? LSA_ROW_SKIP : (unsigned char)tl_mod(tl);
             }
-            launch_ntt(c, ext + (size_t)d * T * N, ext + (size_t)d * T * N, nb, s_ext, T, rm, false, s);
+            launch_ntt(c, ext + (size_t)d * T * N, ext + (size_t)d * T * N, nb, s_ext, s_ext, T, rm, false, s, nullptr, second_pass ? 3 : 1);
         }
     }
 }
@@ -111,7 +124,7 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
 // after the switch, as here, every rotation's residues are the same as if it had been computed on its own)
 static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
-                      const KsRescale* rs, bool coeff_out) {
+                      const KsRescale* rs, bool coeff_out, bool ext_first_pass_only) {
     const long long N = c.n;
     const int L = level + 1, np = c.np, T = L + np, beta = ceil_div(L, np);
     u64* cxi = ws;
@@ -119,8 +132,16 @@ static void ks_finish(Context& c, int level, const u64* cx, long long scx, const
     u64* acc = ext + (size_t)nb * beta * T * N;
     u64* conv = acc + (size_t)nb * 2 * T * N;
     const long long s_ext = (long long)beta * T * N, s_acc = 2LL * T * N, s_conv = 2LL * L * N;
-    // 4. gadget inner product with the key (both halves)
-    launch_ks_mac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s);
+    // 4. gadget inner product with the key (both halves); fused with the extension transform's second pass when ks_decompose
+    //    stopped after the first one
+    if (ext_first_pass_only) {
+        const int eng = ks_fused_engines(c);
+        LSA_REQUIRE(launch_ntt_ksmac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s, eng), "fused key MAC: shape not covered");
+        for (int e = 0; e < 2; e++)
+            if (!((eng >> e) & 1)) launch_ks_mac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s, e);
+    } else {
+        launch_ks_mac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s);
+    }
     // 5. ModDown: P-part out of NTT, centred exact conversion P -> Q, back to NTT, (accQ - conv) * P^-1 (+ base).
     //    coeff_out (BFV: the result is wanted in the coefficient domain and `base` is given there): every row of acc leaves
     //    the NTT domain once and the tail runs on coefficients -- INTT((acc - NTT(conv)) * P^-1) == (INTT(acc) - conv) * P^-1
@@ -219,11 +240,25 @@ static void ks_finish(Context& c, int level, const u64* cx, long long scx, const
     }
 }
 
+// one key per decomposition (relinearisation, a single rotation, a generic switch): the extension transform's second pass
+// and the key MAC run as one kernel where the shape allows (k_ntt_r16_ksmac); hoisted rotations (several keys on one
+// decomposition) keep the two steps apart
+static bool ks_fuse_mac(const Context& c, int level, const Key& key) {
+    const int T = level + 1 + c.np, beta = ceil_div(level + 1, c.np);
+    if (!ks_fused_enabled(c) || !ks_fused_engines(c) || (c.fp64_ntt && !key.fp) || beta * T > LSA_MAX_PERIOD || T > 64) return false;
+    for (int tl = 0; tl < T; tl++) {   // worth it only if some target limb takes the fused kernel
+        const u64 q = c.T.mod[tl <= level ? tl : c.p_mod(tl - level - 1)];
+        const bool fp = c.fp64_ntt && (q >> LSA_FP64_MAX_BITS) == 0;
+        if ((ks_fused_engines(c) >> (fp ? 1 : 0)) & 1) return true;
+    }
+    return false;
+}
 static void key_switch(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                        const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
                        const KsRescale* rs = nullptr) {
-    ks_decompose(c, level, cx, scx, nb, ws, s);
-    ks_finish(c, level, cx, scx, key, p, sp, base, sbase, base_rpp, base_polys, nb, ws, s, rs);
+    const bool fuse = ks_fuse_mac(c, level, key);
+    ks_decompose(c, level, cx, scx, nb, ws, s, nullptr, 0, !fuse);
+    ks_finish(c, level, cx, scx, key, p, sp, base, sbase, base_rpp, base_polys, nb, ws, s, rs, false, fuse);
 }
 
 // ------------------------------------------------------------------------------------------------ rescale
@@ -509,8 +544,9 @@ static void bfv_key_switch(Context& c, int level, const u64* cx, long long scx, 
     u64* cxn = ws;
     u64* sub = ws + (size_t)nb * L * N;
     launch_ntt(c, cx, cxn, nb, scx, (long long)L * N, L, rm_seq(L), false, s);
-    ks_decompose(c, level, cxn, (long long)L * N, nb, sub, s, cx, scx);
-    ks_finish(c, level, cxn, (long long)L * N, key, p, sp, base, sbase, base_rpp, base_polys, nb, sub, s, nullptr, true);
+    const bool fuse = ks_fuse_mac(c, level, key);
+    ks_decompose(c, level, cxn, (long long)L * N, nb, sub, s, cx, scx, !fuse);
+    ks_finish(c, level, cxn, (long long)L * N, key, p, sp, base, sbase, base_rpp, base_polys, nb, sub, s, nullptr, true, fuse);
 }
 
 void bfv_relin(Context& c, int level, const u64* d3, const Key& rlk, u64* out, int batch, long long sd, long long so,

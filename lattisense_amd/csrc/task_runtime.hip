@@ -726,7 +726,7 @@ struct fhe_task_handle_st {
         for (auto& k : keys) {
             const size_t words = (size_t)k.beta * 2 * k.comp * N;
             auto dk = std::make_shared<DevKey>();
-            dk->slab = dslab(words);
+            dk->slab = dslab(ks_fused_enabled(c) ? 2 * words : words);   // (+ the key as doubles behind it, launch_key_prepare)
             segs.push_back({k.off, words, dk->slab->ptr});
             dkeys.push_back(dk);
         }
@@ -749,10 +749,9 @@ struct fhe_task_handle_st {
             dk->key.data = dk->slab->ptr;
             dk->key.level = k.level;
             dk->key.owned = false;
-            RowMap rm;
-            rm.period = k.comp;
-            for (int j = 0; j < k.comp; j++) rm.mod_of[j] = (unsigned char)(j <= k.level ? j : c.p_mod(j - k.level - 1));
-            launch_to_mont(c, dk->key.data, k.beta * 2 * k.comp, rm, s);
+            double* fp = ks_fused_enabled(c) ? reinterpret_cast<double*>(dk->slab->ptr + (size_t)k.beta * 2 * k.comp * N) : nullptr;
+            launch_key_prepare(c, dk->key.data, fp, k.level, s);
+            dk->key.fp = fp;
             avail[k.node->output_nodes[0]->index] = dk;
             last_key_uploads++;
             if (keep_keys) key_cache[{c.device, k.node->output_nodes[0]->index}] = CachedKey{k.handle, k.fingerprint, dk};
@@ -1482,6 +1481,8 @@ struct fhe_task_handle_st {
                         dk->key = key_src[k]->key;
                         dk->key.data = (u64*)table.at(d)[j];
                         dk->key.owned = false;
+                        if (key_src[k]->key.fp)   // the double copy travelled in the same slab
+                            dk->key.fp = reinterpret_cast<const double*>(dk->key.data + (reinterpret_cast<const u64*>(key_src[k]->key.fp) - key_src[k]->key.data));
                         av[key_idx[k]] = dk;
                         if (keep_keys) {
                             auto up = key_cache.find({up_dev, key_idx[k]});
