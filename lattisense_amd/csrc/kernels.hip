@@ -159,11 +159,12 @@ static bool ntt_launch_r16(const NttPassArgs& a, int npass, bool fused, long lon
     const bool pro = fused && a.fz_pro && a.s_lo == 0, epi = fused && a.fz_epi && a.final_reduce;
     const size_t lds_bytes = (size_t)LSA_R16_LDS_WORDS * sizeof(u64);
     const dim3 grid((unsigned)nblocks), block(LSA_R16_THREADS);
-    // the two-operand prologue stays on the staged kernel: with 32 eight-byte loads per thread in front of the first radix
-    // group the register form measured 628 us per launch against 469 (profiles/r03/ab_r16_kernel_stats.log); LSA_R16_PRO=1 for A/B
+    // the two-operand prologue: 394 us per headline launch here against 450 on the staged kernel once the lift's block-uniform
+    // cases became branches (628 before: both lifts were evaluated per element, profiles/r03/ab_r16_prologue_epilogue_branches.log);
+    // LSA_R16_PRO=0 keeps it on the staged kernel (A/B)
     static const bool pro_enabled = [] {
         const char* e = getenv("LSA_R16_PRO");
-        return e && e[0] == '1';
+        return !(e && e[0] == '0');
     }();
     if (a.lambda) {
         if (epi || (pro && !pro_enabled)) return false;   // (a first pass is never the last one of a two-pass plan)

@@ -417,11 +417,24 @@ LSA_HD void ntt_phase_load(const NttPassArgs& a, const NttBlockCtx& bc, int tid,
                 ntt_load_data_pair(g + x, st[2 * p], st[2 * p + 1]);
                 ntt_load_data_pair(gl + x, sl[2 * p], sl[2 * p + 1]);
             }
+            if (f.fp_lift) {   // (block-uniform: a branch around the loop, not a select per element between this and the integer lift)
 #pragma unroll
-            for (int p = 0; p < CH; p++) {
-                const int l = 2 * (tid + (p0 + p) * NT);
-                lds[lds_addr(l)] = ntt_load_fix(f, st[2 * p], sl[2 * p]);
-                lds[lds_addr(l + 1)] = ntt_load_fix(f, st[2 * p + 1], sl[2 * p + 1]);
+                for (int p = 0; p < CH; p++) {
+                    const int l = 2 * (tid + (p0 + p) * NT);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const double td = u52_to_double(sl[2 * p + h]);
+                        const double r = td > f.hd ? td - f.qld : td;
+                        lds[lds_addr(l + h)] = d_to_bits(u52_to_double(st[2 * p + h]) + r);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < CH; p++) {
+                    const int l = 2 * (tid + (p0 + p) * NT);
+                    lds[lds_addr(l)] = ntt_load_fix(f, st[2 * p], sl[2 * p]);
+                    lds[lds_addr(l + 1)] = ntt_load_fix(f, st[2 * p + 1], sl[2 * p + 1]);
+                }
             }
         }
         return;

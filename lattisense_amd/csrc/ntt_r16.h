@@ -161,8 +161,19 @@ LSA_HD void r16_load_direct(const NttPassArgs& a, const NttBlockCtx& bc, int tid
                 v[e] = r16_load1(g + x);
                 t[e] = r16_load1(gl + x);
             }
+            // the block-uniform cases of ntt_load_fix as branches around the loop (inside it the compiler evaluates both the
+            // FP64 lift and the integer lift -- a general reduction -- for every element and selects)
+            if (f.fp_lift) {
 #pragma unroll
-            for (int e = 8 * h; e < 8 * h + 8; e++) v[e] = ntt_load_fix(f, v[e], t[e]);
+                for (int e = 8 * h; e < 8 * h + 8; e++) {
+                    const double td = u52_to_double(t[e]);
+                    const double r = td > f.hd ? td - f.qld : td;
+                    v[e] = d_to_bits(u52_to_double(v[e]) + r);
+                }
+            } else {
+#pragma unroll
+                for (int e = 8 * h; e < 8 * h + 8; e++) v[e] = ntt_load_fix(f, v[e], t[e]);
+            }
         }
         return;
     }
@@ -291,10 +302,32 @@ LSA_HD void r16_store_coalesced(const NttPassArgs& a, const NttBlockCtx& bc, int
             if (FZ && f.tail) ntt_load_data_pair(pa + xs[m], va[2 * m], va[2 * m + 1]);
             if (FZ && f.with_base) ntt_load_data_pair(pb + xs[m], vb[2 * m], vb[2 * m + 1]);
         }
+        // the block-uniform cases of ntt_store_fix as branches around the loop: FP64 limb with the merged tail (the headline's
+        // epilogue), FP64 limb plain, everything else through the general function
+        u64 w[2 * LSA_NTT_STORE_CHUNK];
+        if (f.fp && !f.raw && FZ && f.tail && f.merged) {
 #pragma unroll
-        for (int m = 0; m < LSA_NTT_STORE_CHUNK; m++)
-            ntt_store_pair(g + xs[m], ntt_store_fix(f, v[2 * m], va[2 * m], vb[2 * m]),
-                           ntt_store_fix(f, v[2 * m + 1], va[2 * m + 1], vb[2 * m + 1]));
+            for (int j = 0; j < 2 * LSA_NTT_STORE_CHUNK; j++) {
+                double r = f.skip_reduce ? d_from_bits(v[j]) : fp_reduce(d_from_bits(v[j]), f.qd, f.qinvd);
+                const double ad = u52_to_double(va[j]), bd = f.with_base ? u52_to_double(vb[j]) : 0.0;
+                r = fp_modmul(fp_modmul(ad, f.kd, f.qd, f.qinvd) - r + bd, f.k2d, f.qd, f.qinvd);
+                r = fp_reduce(r, f.qd, f.qinvd);
+                if (r < 0) r += f.qd;
+                w[j] = double_to_u52(r);
+            }
+        } else if (f.fp && !f.raw && !(FZ && f.tail)) {
+#pragma unroll
+            for (int j = 0; j < 2 * LSA_NTT_STORE_CHUNK; j++) {
+                double r = f.skip_reduce ? d_from_bits(v[j]) : fp_reduce(d_from_bits(v[j]), f.qd, f.qinvd);
+                if (r < 0) r += f.qd;
+                w[j] = double_to_u52(r);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * LSA_NTT_STORE_CHUNK; j++) w[j] = ntt_store_fix(f, v[j], va[j], vb[j]);
+        }
+#pragma unroll
+        for (int m = 0; m < LSA_NTT_STORE_CHUNK; m++) ntt_store_pair(g + xs[m], w[2 * m], w[2 * m + 1]);
     }
 }
 
