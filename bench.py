@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--tile", type=int, default=-1, help="ciphertexts per kernel wave (-1 = library default)")
     ap.add_argument("--ntt-chunk-mib", type=int, default=-1, help="Infinity-Cache chunk of two-pass NTTs (-1 = default)")
     ap.add_argument("--int-ntt", action="store_true", help="force the integer butterfly engine (A/B)")
-    ap.add_argument("--dual-stream", action="store_true", help="overlap alternate tiles on an auxiliary stream (A/B)")
+    ap.add_argument("--dual-stream", action="store_true", help="(default for the operator workloads) alternate tiles of an operator on an auxiliary stream")
+    ap.add_argument("--single-stream", action="store_true", help="one stream for the timed region too (A/B); the roofline sample is always taken single-stream")
     ap.add_argument("--no-fuse", action="store_true", help="separate ModDown/rescale tail kernels (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pinned-alloc", action="store_true", help="task workloads: caller buffers from lsa_host_alloc, copied without staging (A/B: slower on the measured hosts)")
@@ -467,8 +468,12 @@ def main():
         check(L_.lsa_set_ntt_chunk_mib(ctx.h, args.ntt_chunk_mib))
     if args.int_ntt:
         ctx.set_fp64_ntt(False)
-    if args.dual_stream:
-        check(L_.lsa_set_dual_stream(ctx.h, 1))
+    # The timed region runs the operator's tiles alternately on two streams (each kernel of the pipeline uses part of the chip:
+    # two tiles in flight fill each other's gaps, +2-3 % on the headline, profiles/r03/ab_dual_stream_fused_build.log); per-kernel
+    # durations are only attributable when one kernel runs at a time, so the roofline / kernel breakdown come from a SECOND,
+    # single-stream measured region of the same run (reported next to the headline as `single_stream`).
+    dual = args.workload != "ntt" and not args.single_stream
+    check(L_.lsa_set_dual_stream(ctx.h, 1 if dual else 0))
     if args.no_fuse:
         check(L_.lsa_set_fuse_tails(ctx.h, 0))
 
@@ -532,14 +537,33 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    check(L_.lsa_profile_begin(ctx.h, args.prof_stride))
+    if not dual:
+        check(L_.lsa_profile_begin(ctx.h, args.prof_stride))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    check(L_.lsa_profile_end(ctx.h))
+    if not dual:
+        check(L_.lsa_profile_end(ctx.h))
     dt = sharding.max_over_ranks(dt, device=dev)
+    single = None
+    if dual:
+        # second measured region: one stream, HIP-event samples around the kernels (roofline, kernel breakdown)
+        check(L_.lsa_set_dual_stream(ctx.h, 0))
+        k2 = max(2, min(args.steps, 10))
+        step()
+        barrier()
+        check(L_.lsa_profile_begin(ctx.h, args.prof_stride))
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        barrier()
+        dt1 = time.perf_counter() - t1
+        check(L_.lsa_profile_end(ctx.h))
+        dt1 = sharding.max_over_ranks(dt1, device=dev)
+        single = {"value": world * batch * k2 / dt1, "ms_per_step": dt1 / k2 * 1e3, "steps": k2}
+    prof_steps = single["steps"] if single else args.steps
 
     ms_per_step = dt / args.steps * 1e3
     if args.workload == "ntt":
@@ -560,15 +584,26 @@ def main():
     for kid, name in kinds.items():
         ms, by, ns, nl = prof(kid)
         if ns:
-            breakdown[name] = {"est_ms_per_step": ms / ns * nl / args.steps, "avg_launch_us": ms / ns * 1e3,
-                               "achieved_GBps": by / ms / 1e6, "launches_per_step": nl / args.steps}
+            breakdown[name] = {"est_ms_per_step": ms / ns * nl / prof_steps, "avg_launch_us": ms / ns * 1e3,
+                               "achieved_GBps": by / ms / 1e6, "launches_per_step": nl / prof_steps}
     ntt = breakdown.get("k_ntt_pass", None)
+    ntt_primary = None
+    if ntt:
+        ms0, _, _, _ = prof(0)
+        byp = ctypes.c_double()
+        check(L_.lsa_profile_read_primary(ctx.h, 0, ctypes.byref(byp)))
+        ntt_primary = byp.value / ms0 / 1e6
     roofline = None
     if ntt:
         roofline = {"kernel": "k_ntt_r16 / k_ntt_pass (limb-transform passes)", "bound": "hbm", "achieved": ntt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": ntt["achieved_GBps"] / HBM_PEAK_GBPS, "traffic": None,
                     "avg_launch_us": ntt["avg_launch_us"], "launches_per_step": ntt["launches_per_step"],
-                    "sampling": "HIP event pair around one launch in %d (hash-picked), on the launch stream" % args.prof_stride}
+                    # `achieved` counts the algorithmic bytes of everything these launches do: the transform passes (16 N / 2 per
+                    # limb and pass) AND, for the fused second pass + key MAC launches, the key MAC's bytes as k_ks_mac counts them;
+                    # the transforms' bytes alone over the same durations:
+                    "achieved_transform_bytes_only": ntt_primary, "frac_transform_bytes_only": ntt_primary / HBM_PEAK_GBPS,
+                    "sampling": "HIP event pair around one launch in %d (hash-picked), on the launch stream%s" % (
+                        args.prof_stride, "; single-stream region of the same run (the timed region overlaps two tiles)" if single else "")}
 
     # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 wraps the process); they
     # come from the committed --pmc passes of this same command (tools/profile.sh + tools/pmc_traffic.py -> profiles/rNN/),
@@ -602,6 +637,7 @@ def main():
             "config": {"workload": cfg["label"], "batch_per_gpu": batch, "ring_degree": n, "q_limbs": L,
                        "special_primes": len(cfg["p"]), "sharding": "ciphertext batch by rank; key broadcast once"},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+            "tile_streams": 2 if dual else 1, "single_stream": single,
             "build_flags": L_.lsa_build_flags().decode(),   # "" = the product library (csrc/build_flags.h)
         }
         print(json.dumps(line), flush=True)

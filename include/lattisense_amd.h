@@ -179,6 +179,7 @@ int lsa_profile_begin(lsa_context ctx, int stride);
 int lsa_profile_end(lsa_context ctx);
 int lsa_profile_read(lsa_context ctx, int kind, double* total_ms, double* total_bytes, long long* sampled,
                      long long* launched);
+int lsa_profile_read_primary(lsa_context ctx, int kind, double* total_bytes_primary);
 /* micro-benchmark kernels used by bench.py / DESIGN.md to report the integer-multiply and copy ceilings */
 int lsa_probe_copy(lsa_context ctx, uint64_t* dst, const uint64_t* src, size_t n_u64, void* stream);
 int lsa_probe_mulhi(lsa_context ctx, uint64_t* buf, size_t n_u64, int iters, void* stream);

@@ -101,6 +101,7 @@ SIGNATURES = {
     "lsa_profile_end": (c_int, [c_vp]),
     "lsa_profile_read": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(c_ll), ctypes.POINTER(c_ll)]),
+    "lsa_profile_read_primary": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double)]),
     "lsa_probe_copy": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "lsa_probe_mulhi": (c_int, [c_vp, c_vp, ctypes.c_size_t, c_int, c_vp]),
 }

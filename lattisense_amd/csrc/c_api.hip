@@ -350,6 +350,19 @@ int lsa_profile_read(lsa_context ctx, int kind, double* total_ms, double* total_
     });
 }
 
+// the same samples with only the kind's OWN algorithmic bytes (a fused launch -- the transform pass that also performs the key
+// MAC -- counts both functions' bytes in lsa_profile_read and the transform's alone here)
+int lsa_profile_read_primary(lsa_context ctx, int kind, double* total_bytes_primary) {
+    return guard([&] {
+        Context& c = C(ctx);
+        LSA_REQUIRE(kind >= 0 && kind < LSA_PROF_KINDS && total_bytes_primary, "bad argument");
+        double by = 0;
+        for (auto& sm : c.prof_samples)
+            if (sm.kid == kind) by += sm.bytes_primary;
+        *total_bytes_primary = by;
+    });
+}
+
 int lsa_set_fuse_tails(lsa_context ctx, int enable) {
     return guard([&] { C(ctx).fuse_tails = enable ? 1 : 0; });
 }

@@ -329,7 +329,8 @@ bool launch_ntt_ksmac(Context& c, int level, const u64* cx, long long scx, u64* 
         if (!g.n_tl) continue;
         const long long nblocks = (long long)batch * g.n_tl * (1 << (c.logn - 12));
         LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
-        ProfScope ps(c, PROF_NTT, 16.0 * c.n * transforms * batch / 2 + 8.0 * c.n * g.n_tl * (batch * ((double)g.beta + 2.0) + 2.0 * g.beta), s);
+        const double ntt_bytes = 16.0 * c.n * transforms * batch / 2;
+        ProfScope ps(c, PROF_NTT, ntt_bytes + 8.0 * c.n * g.n_tl * (batch * ((double)g.beta + 2.0) + 2.0 * g.beta), s, ntt_bytes);
         const dim3 grid((unsigned)nblocks), block(LSA_R16_THREADS);
         if (mu == 8 && eng) hipLaunchKernelGGL((k_ntt_r16_ksmac<8, true>), grid, block, lds_bytes, s, g);
         else if (mu == 8) hipLaunchKernelGGL((k_ntt_r16_ksmac<8, false>), grid, block, lds_bytes, s, g);

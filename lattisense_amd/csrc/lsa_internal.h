@@ -116,6 +116,7 @@ struct Context {
         hipEvent_t e0, e1;
         int kid;
         double bytes;
+        double bytes_primary;   // the kind's own function only (a fused launch also does another kernel's work: `bytes` counts both)
     };
     bool prof_on = false;
     int prof_stride = 1;
@@ -160,7 +161,7 @@ struct ProfScope {
     hipStream_t s;
     bool active = false;
     Context::ProfSample smp{};
-    ProfScope(Context& c_, int kid, double bytes, hipStream_t s_) : c(c_), s(s_) {
+    ProfScope(Context& c_, int kid, double bytes, hipStream_t s_, double bytes_primary = -1.0) : c(c_), s(s_) {
         if (!c.prof_on) return;
         const long long idx = c.prof_launched[kid]++;
         // every stride-th launch on average, picked by a hash of the launch index: a fixed stride would lock onto the
@@ -180,6 +181,7 @@ struct ProfScope {
         smp.e1 = take();
         smp.kid = kid;
         smp.bytes = bytes;
+        smp.bytes_primary = bytes_primary < 0 ? bytes : bytes_primary;
         LSA_HIP(hipEventRecord(smp.e0, s));
         active = true;
     }

@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/statsq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" > $OUT/bench.json 2> $OUT/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/bench.py --no-cpu-baseline --single-stream --steps 4 --warmup 1 "$@" > $OUT/bench.json 2> $OUT/err.log
 cd $REPO && python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 f = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_stats.csv"), recursive=True))[-1]
