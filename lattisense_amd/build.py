@@ -71,7 +71,7 @@ def build_variant(name, flags, verbose=False):
     *_COMPUTE_ONLY) get -DLSA_DIAG_BUILD and the library its own SONAME: it cannot stand in for the product."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     build_native()
-    diag = any(t in flags for t in ("_DIAG_NO_", "_DIAG_COPY_ONLY", "_DIAG_COMPUTE_ONLY"))
+    diag = any(t in flags for t in ("_DIAG_NO_", "_DIAG_COPY_ONLY", "_DIAG_COMPUTE_ONLY", "_DIAG_TW8"))
     if diag and "-DLSA_DIAG_BUILD" not in flags:
         flags = flags + " -DLSA_DIAG_BUILD"
     flags = flags + " -DLSA_VARIANT_NAME=" + name

@@ -10,7 +10,7 @@
 // (liblattisense_amd_diag_<name>.so): such an object can never be mistaken for the product.
 #pragma once
 
-#if (defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS) || defined(LSA_NTT_DIAG_COPY_ONLY) || defined(LSA_NTT_DIAG_COMPUTE_ONLY) ||        \
+#if (defined(LSA_NTT_DIAG_NO_TWIDDLE_LOADS) || defined(LSA_NTT_DIAG_COPY_ONLY) || defined(LSA_NTT_DIAG_COMPUTE_ONLY) || defined(LSA_NTT_DIAG_TW8) || \
      defined(LSA_KS_DIAG_NO_MATH) || defined(LSA_KS_DIAG_NO_STORE) || defined(LSA_BC_DIAG_NO_MATH) || defined(LSA_BC_DIAG_NO_STORE)) && \
     !defined(LSA_DIAG_BUILD)
 #error "wrong-result diagnostic switches need -DLSA_DIAG_BUILD (use lattisense_amd.build --variant: it adds the flag and renames the library)"
@@ -161,6 +161,11 @@
 #else
 #define LSA_BF_AC ""
 #endif
+#ifdef LSA_NTT_DIAG_TW8
+#define LSA_BF_AD " LSA_NTT_DIAG_TW8"
+#else
+#define LSA_BF_AD ""
+#endif
 #ifdef LSA_VARIANT_NAME
 #define LSA_BF_V " variant=" LSA_BF_STR(LSA_VARIANT_NAME)
 #else
@@ -175,4 +180,4 @@
 // (leading blank stripped by lsa_build_flags)
 #define LSA_BUILD_FLAGS_TEXT                                                                                              \
     LSA_BF_DIAG LSA_BF_A LSA_BF_B LSA_BF_C LSA_BF_D LSA_BF_E LSA_BF_F LSA_BF_G LSA_BF_H LSA_BF_I LSA_BF_J LSA_BF_K LSA_BF_L \
-        LSA_BF_M LSA_BF_N LSA_BF_O LSA_BF_P LSA_BF_Q LSA_BF_R LSA_BF_S LSA_BF_T LSA_BF_U LSA_BF_V LSA_BF_W LSA_BF_X LSA_BF_Y LSA_BF_Z LSA_BF_AA LSA_BF_AB LSA_BF_AC
+        LSA_BF_M LSA_BF_N LSA_BF_O LSA_BF_P LSA_BF_Q LSA_BF_R LSA_BF_S LSA_BF_T LSA_BF_U LSA_BF_V LSA_BF_W LSA_BF_X LSA_BF_Y LSA_BF_Z LSA_BF_AA LSA_BF_AB LSA_BF_AC LSA_BF_AD

@@ -610,6 +610,17 @@ LSA_HD void ntt_group_int_impl(u64 (&v)[1 << RHO], bool inverse, const u64* tw /
             const int s = s_base + j;
             const u64* tws = tw + 2 * (1LL << s);
             u64 w[E / 2], ws[E / 2];   // this stage's 2^j twiddle pairs, one 16-byte load each
+#if defined(LSA_NTT_DIAG_TW8)   // diagnostic build: 8-byte twiddles in the FP64 table's layout (wrong results, same arithmetic)
+            if (!TWU) {
+                double wd[E / 2];
+                ntt_load_tw_fp(reinterpret_cast<const double*>(tw) + (1LL << s), s, j, G, wd);
+#pragma unroll
+                for (int k = 0; k < (1 << j); k++) {
+                    w[k] = (u64)__builtin_bit_cast(long long, wd[k]);
+                    ws[k] = (w[k] << 3) | 1;
+                }
+            } else
+#endif
 #pragma unroll
             for (int k = 0; k < (1 << j); k++) {
                 if (TWU) {   // wave-uniform position: scalar loads
@@ -672,6 +683,17 @@ LSA_HD void ntt_group_int_impl(u64 (&v)[1 << RHO], bool inverse, const u64* tw /
             }
             const u64* tws = tw + 2 * (1LL << s);
             u64 w[E / 2], ws[E / 2];
+#if defined(LSA_NTT_DIAG_TW8)   // diagnostic build: 8-byte twiddles in the FP64 table's layout (wrong results, same arithmetic)
+            if (!TWU) {
+                double wd[E / 2];
+                ntt_load_tw_fp(reinterpret_cast<const double*>(tw) + (1LL << s), s, j, G, wd);
+#pragma unroll
+                for (int k = 0; k < (1 << j); k++) {
+                    w[k] = (u64)__builtin_bit_cast(long long, wd[k]);
+                    ws[k] = (w[k] << 3) | 1;
+                }
+            } else
+#endif
 #pragma unroll
             for (int k = 0; k < (1 << j); k++) {
                 if (TWU) {   // wave-uniform position: scalar loads

@@ -1,4 +1,4 @@
-"""Randomised GPU-vs-oracle differential run over parameter shapes the fixed tests do not enumerate: ring degrees 2^12..2^15,
+"""Randomised GPU-vs-oracle differential run over parameter shapes the fixed tests do not enumerate: ring degrees 2^12..2^16,
 1..4 special primes, prime chains cut from the reference's CKKS / BFV / bootstrap sets (46-, 56-, 40-, 60-, 61-bit limbs mixed),
 random levels and key levels, edge-value inputs (zeros, q-1 everywhere).  Every comparison is bit-exact.
 usage: python tools/fuzz_parity.py [cases] [seed]"""
@@ -33,11 +33,11 @@ def rand_limbs(mods, shape, n, mode):
 t0 = time.time()
 done = {"ckks_hmult": 0, "ckks_rotate": 0, "bfv_hmult": 0, "bfv_rotate": 0}
 for case in range(cases):
-    logn = int(rng.integers(12, 16))
+    bfv = case % 3 == 2
+    logn = int(rng.integers(12, 16 if bfv else 17))   # CKKS: up to 2^16 (the chains' primes are 1 mod 2^17), BFV: up to 2^15
     n = 1 << logn
     nq = int(rng.integers(2, 9))
     np_ = int(rng.integers(1, 5))
-    bfv = case % 3 == 2
     if bfv:
         q = [int(x) for x in rng.permutation(F["q"])[: min(nq, len(F["q"]))]]
         p = [int(x) for x in rng.permutation(F["p"] + B["p"][:2])[:np_]]
