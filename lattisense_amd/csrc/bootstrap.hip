@@ -30,6 +30,11 @@ void ckks_rotate_many(Context&, int, const u64*, int, const u64*, const Key* con
                       hipStream_t);
 void ckks_mult_relin_rescale(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long, long long,
                              hipStream_t);
+void ckks_lift_ext(Context&, int, const u64*, u64*, int, long long, long long, hipStream_t);
+void ckks_rotate_many_ext(Context&, int, const u64*, int, const u64*, const Key* const*, u64* const*, int, long long, long long,
+                          hipStream_t);
+void ckks_rotate_ext(Context&, int, const u64*, u64, const Key&, u64*, bool, int, long long, long long, hipStream_t);
+void ckks_moddown_ext(Context&, int, u64*, u64*, int, long long, long long, hipStream_t);
 
 using cplx = std::complex<double>;
 using Diags = std::map<int, std::vector<cplx>>;   // diagonal k: d[t] multiplies x[(t + k) mod n]
@@ -226,7 +231,8 @@ struct BtMatrix {
     int period = 0;                      // period of the diagonals (index arithmetic mod period); N/2 for dense packing
     bool naive = false;
     std::vector<int> ks;                 // diagonal indices, ascending
-    std::vector<u64*> plains;            // per diagonal: NTT-domain plaintext [level+1][N] of rot_{-giant}(diag)
+    std::vector<u64*> plains;            // per diagonal: NTT-domain plaintext [rows][N] of rot_{-giant}(diag)
+    int rows = 0;                        // level + 1, or level + 1 + k (the special primes too) for a double-hoisted matrix
 };
 
 struct Bootstrap {
@@ -241,6 +247,9 @@ struct Bootstrap {
     int sine_deg = 30, arcsine_deg = 0;  // reference: btp_eval_mod_sine_deg / _arcsine_deg (gpu_wrapper.cu:100-103)
     int cheb_depth = 5, asin_depth = 0;  // levels of the cosine interpolant (ceil log2(sine_deg + 1)) and of the arcsine polynomial
     std::vector<double> asin_coef;       // arcsine Taylor coefficients in the monomial basis, padded to 2^asin_depth (empty: none)
+    // baby-step / giant-step matrices keep their sums over Q u P and divide by P once per giant step + once at the end
+    // (Lattigo's MultiplyByDiagMatrixBSGS); LSA_BT_DOUBLE_HOIST=0 at plan creation: one division per rotation (A/B)
+    bool double_hoist = true;
     int evalmod_depth() const { return cheb_depth + r + asin_depth; }
     u64* mono[2] = {nullptr, nullptr};   // NTT of +X^(N/2) and -X^(N/2), [top_level+1][N]
     std::vector<u64> galois;             // Galois elements a run needs (rotations + conjugation)
@@ -268,14 +277,17 @@ struct Bootstrap {
     }
 
     // real polynomial coefficients * scale -> NTT-domain plaintext on the device
-    u64* upload_plain(const std::vector<double>& coef, double scale, int level, hipStream_t s) {
-        const int L = level + 1;
+    // ext: the same integer polynomial at the special primes too, rows level+1 .. level+k (operand of extended ciphertexts)
+    u64* upload_plain(const std::vector<double>& coef, double scale, int level, hipStream_t s, bool ext = false) {
+        const int L = level + 1 + (ext ? c.np : 0);
         const size_t N = (size_t)c.n;
         std::vector<u64> host((size_t)L * N);
+        RowMap rm = rm_limbs(L);
+        for (int j = level + 1; j < L; j++) rm.mod_of[j] = (unsigned char)c.p_mod(j - level - 1);
         for (size_t x = 0; x < N; x++) {
             const long long v = round_even(coef[x] * scale);
             for (int j = 0; j < L; j++) {
-                const long long q = (long long)c.T.mod[j];
+                const long long q = (long long)c.T.mod[rm.mod_of[j]];
                 long long r = v % q;
                 if (r < 0) r += q;
                 host[(size_t)j * N + x] = (u64)r;
@@ -285,7 +297,7 @@ struct Bootstrap {
         LSA_HIP(hipMalloc((void**)&d, host.size() * sizeof(u64)));
         owned.push_back(d);
         LSA_HIP(hipMemcpyAsync(d, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice, s));
-        launch_ntt(c, d, d, 1, (long long)L * N, L, rm_limbs(L), false, s);
+        launch_ntt(c, d, d, 1, (long long)L * N, L, rm, false, s);
         LSA_HIP(hipStreamSynchronize(s));   // `host` goes out of scope
         return d;
     }
@@ -304,6 +316,7 @@ struct Bootstrap {
     void build(hipStream_t s) {
         const int n = c.n / 2;
         top_level = c.nq - 1;
+        if (const char* e = std::getenv("LSA_BT_DOUBLE_HOIST")) double_hoist = e[0] != '0';
         LSA_REQUIRE(c.algo == LSA_ALGO_CKKS, "bootstrap: CKKS only");
         LSA_REQUIRE(sine_deg >= 1 && sine_deg <= 63, "bootstrap: sine degree outside 1..63");
         LSA_REQUIRE(arcsine_deg >= 0 && arcsine_deg <= 15 && (arcsine_deg == 0 || (arcsine_deg & 1)), "bootstrap: arcsine degree must be odd and at most 15");
@@ -414,12 +427,14 @@ struct Bootstrap {
             bm.naive = bm.ks.size() < 3;
             bm.n1 = bm.naive ? 1 : bsgs_split(bm.ks, period, 2.0);
             const double pt_scale = (double)c.T.mod[bm.level];
+            const bool ext = double_hoist && !bm.naive;
+            bm.rows = bm.level + 1 + (ext ? c.np : 0);
             for (int k : bm.ks) {
                 const int giant = bm.naive ? 0 : (k / bm.n1) * bm.n1;
                 const std::vector<cplx>& d = mat.at(k);
                 std::vector<cplx> rolled(n);
                 for (int t = 0; t < n; t++) rolled[t] = d[(((t - giant) % period) + period) % period];   // rot_{-giant}(diag), tiled
-                bm.plains.push_back(upload_plain(slots_to_coeffs(rolled, rg), pt_scale, bm.level, s));
+                bm.plains.push_back(upload_plain(slots_to_coeffs(rolled, rg), pt_scale, bm.level, s, ext));
                 const int baby = bm.naive ? k : k - giant;
                 if (baby) gal[gel(baby)] = true;
                 if (giant) gal[gel(giant)] = true;
@@ -501,7 +516,12 @@ struct Eval {
         : c(c_), bt(b), s(s_), m(m_), rlk(rlk_), glk(g), pool(b.pool), N(c_.n) {}
     long long stride(int level) const { return 2LL * (level + 1) * N; }
     DCt alloc(int level, double scale) {
-        const size_t words = (size_t)m * stride(level);
+        DCt o = alloc_words((size_t)m * stride(level));
+        o.level = level;
+        o.scale = scale;
+        return o;
+    }
+    DCt alloc_words(size_t words) {
         auto b = std::make_shared<DBuf>();
         b->words = words;
         b->pool = &pool;
@@ -513,7 +533,23 @@ struct Eval {
             LSA_HIP(hipMalloc((void**)&b->p, words * sizeof(u64)));
             bt.pool_all.push_back(b->p);
         }
-        return DCt{b, level, scale};
+        return DCt{b, 0, 0.0};
+    }
+    // extended ciphertext [2][level+1+k][N] over Q_level u P (ops.hip, ckks_rotate_many_ext); `level` and `scale` as for the
+    // ciphertext it will be divided down to
+    long long stride_ext(int level) const { return 2LL * (level + 1 + c.np) * N; }
+    DCt alloc_ext(int level, double scale) {
+        DCt o = alloc_words((size_t)m * stride_ext(level));
+        o.level = level;
+        o.scale = scale;
+        return o;
+    }
+    RowMap rm_ext(int level) const {   // both polynomials' rows of an extended ciphertext
+        RowMap rm;
+        rm.period = level + 1 + c.np;
+        for (int j = 0; j <= level; j++) rm.mod_of[j] = (unsigned char)j;
+        for (int i = 0; i < c.np; i++) rm.mod_of[level + 1 + i] = (unsigned char)c.p_mod(i);
+        return rm;
     }
     RowMap rm2(int level) const {   // both polynomials' limbs
         RowMap rm;
@@ -594,6 +630,41 @@ struct Eval {
                          stride(a.level), s);
         return out;
     }
+    u64 galois_of(int r) const {
+        u64 e = 1;
+        for (int i = 0; i < r; i++) e = e * 5 % (2ULL * c.n);
+        return e;
+    }
+    // the same rotations WITHOUT their division by P: extended ciphertexts (step 0: the ciphertext times P)
+    std::map<int, DCt> rotate_many_ext(const DCt& a, const std::vector<int>& steps) {
+        const int n = c.n / 2;
+        std::map<int, DCt> out;
+        std::vector<u64> els;
+        std::vector<const Key*> keys;
+        std::vector<u64*> ptrs;
+        for (int r0 : steps) {
+            const int r = ((r0 % n) + n) % n;
+            if (out.count(r)) continue;
+            DCt o = alloc_ext(a.level, a.scale);
+            out[r] = o;
+            if (r == 0) {
+                ckks_lift_ext(c, a.level, a.data(), o.data(), m, stride(a.level), stride_ext(a.level), s);
+                continue;
+            }
+            const u64 e = galois_of(r);
+            els.push_back(e);
+            keys.push_back(&gkey(e));
+            ptrs.push_back(o.data());
+        }
+        ckks_rotate_many_ext(c, a.level, a.data(), (int)els.size(), els.data(), keys.data(), ptrs.data(), m, stride(a.level),
+                             stride_ext(a.level), s);
+        return out;
+    }
+    DCt moddown(const DCt& a) {   // extended -> ciphertext; `a` is consumed
+        DCt o = alloc(a.level, a.scale);
+        ckks_moddown_ext(c, a.level, a.data(), o.data(), m, stride_ext(a.level), stride(a.level), s);
+        return o;
+    }
     DCt conj(const DCt& a) {
         const u64 e = 2ULL * c.n - 1;
         DCt o = alloc(a.level, a.scale);
@@ -672,8 +743,91 @@ struct Eval {
         return o;
     }
 
+    // Baby-step / giant-step with the sums kept over Q u P ("double hoisting", Lattigo v4 ckks/linear_transform.go
+    // MultiplyByDiagMatrixBSGS; oracle twin: oracle/ckks_bootstrap.py linear_transform, double_hoist): the baby-step rotations
+    // are gadget products without their division by P, the plaintexts carry the special primes' residues, each giant step's
+    // inner sum is divided once, rotated without division into the running sum, and that sum is divided once:
+    // (giant steps + 1) ModDowns instead of (baby steps + giant steps).
+    DCt linear_transform_dh(const DCt& ct, const BtMatrix& mt, bool do_rescale) {
+        const double pt_scale = q(ct.level);
+        const int T = ct.level + 1 + c.np;
+        std::vector<int> steps;
+        for (int k : mt.ks) steps.push_back(k % mt.n1);
+        std::map<int, DCt> babies = rotate_many_ext(ct, steps);
+        std::map<int, std::vector<size_t>> by_giant;
+        for (size_t i = 0; i < mt.ks.size(); i++) by_giant[(mt.ks[i] / mt.n1) * mt.n1].push_back(i);
+        std::vector<int> bsteps, gsteps;
+        std::vector<const u64*> cp;
+        std::vector<long long> cs;
+        for (auto& kv : babies) {
+            bsteps.push_back(kv.first);
+            cp.push_back(kv.second.data());
+            cs.push_back(stride_ext(ct.level));
+        }
+        const int nb = (int)bsteps.size(), ng = (int)by_giant.size();
+        std::vector<const u64*> pp((size_t)ng * nb, nullptr);
+        std::vector<DCt> inner;
+        std::vector<u64*> op;
+        int gi = 0;
+        for (auto& kv : by_giant) {
+            for (size_t i : kv.second) {
+                const int bi = (int)(std::find(bsteps.begin(), bsteps.end(), mt.ks[i] - kv.first) - bsteps.begin());
+                LSA_REQUIRE(bi < nb, "bootstrap: baby step without its rotation");
+                pp[(size_t)gi * nb + bi] = mt.plains[i];
+            }
+            inner.push_back(alloc_ext(ct.level, ct.scale * pt_scale));
+            op.push_back(inner.back().data());
+            gsteps.push_back(kv.first);
+            gi++;
+        }
+        if (nb <= LSA_MACM_MAX && ng <= LSA_MACM_MAX) {
+            launch_mac_plain_multi(c, nb, cp.data(), cs.data(), ng, pp.data(), op.data(), stride_ext(ct.level), m, 2, T, rm_ext(ct.level), s);
+        } else {
+            for (int g2 = 0; g2 < ng; g2++) {   // wide matrices: one giant step per launch, LSA_MAC_MAX_TERMS products each
+                std::vector<int> bi;
+                for (int b = 0; b < nb; b++)
+                    if (pp[(size_t)g2 * nb + b]) bi.push_back(b);
+                for (size_t i0 = 0; i0 < bi.size(); i0 += LSA_MAC_MAX_TERMS) {
+                    const int cnt = (int)std::min<size_t>(LSA_MAC_MAX_TERMS, bi.size() - i0);
+                    const u64* tc[LSA_MAC_MAX_TERMS];
+                    const u64* tp[LSA_MAC_MAX_TERMS];
+                    long long ts[LSA_MAC_MAX_TERMS], tz[LSA_MAC_MAX_TERMS];
+                    for (int i = 0; i < cnt; i++) {
+                        tc[i] = cp[bi[i0 + i]];
+                        ts[i] = stride_ext(ct.level);
+                        tp[i] = pp[(size_t)g2 * nb + bi[i0 + i]];
+                        tz[i] = 0;
+                    }
+                    launch_mac_plain(c, cnt, tc, ts, tp, tz, i0 ? op[g2] : nullptr, stride_ext(ct.level), op[g2], stride_ext(ct.level), m, 2, T,
+                                     rm_ext(ct.level), s);
+                }
+            }
+        }
+        babies.clear();
+        DCt acc;
+        bool have = false;
+        const int n = c.n / 2;
+        for (int g2 = 0; g2 < ng; g2++) {
+            const int r = ((gsteps[g2] % n) + n) % n;
+            if (r == 0) {
+                LSA_REQUIRE(!have, "bootstrap: giant step 0 must come first");
+                acc = inner[g2];
+                have = true;
+                continue;
+            }
+            DCt iq = moddown(inner[g2]);
+            if (!have) acc = alloc_ext(ct.level, ct.scale * pt_scale);
+            const u64 e = galois_of(r);
+            ckks_rotate_ext(c, ct.level, iq.data(), e, gkey(e), acc.data(), have, m, stride(ct.level), stride_ext(ct.level), s);
+            have = true;
+        }
+        DCt res = moddown(acc);
+        return do_rescale ? rescale(res) : res;
+    }
+
     DCt linear_transform(const DCt& ct, const BtMatrix& mt, bool do_rescale = true) {
         LSA_REQUIRE(ct.level == mt.level, "bootstrap: linear transform applied at an unexpected level");
+        if (!mt.naive && mt.rows > ct.level + 1) return linear_transform_dh(ct, mt, do_rescale);
         const double pt_scale = q(ct.level);
         const int L = ct.level + 1;
         // every baby step is a rotation of the SAME ciphertext: one decomposition serves them all
@@ -963,7 +1117,8 @@ const std::vector<double>& bootstrap_arcsine(const Bootstrap& bt) { return bt.as
 int bootstrap_matrices(const Bootstrap& bt) { return (int)(bt.cts.size() + bt.stc.size()) + (bt.sparse ? 2 : 0); }
 int bootstrap_cts_matrices(const Bootstrap& bt) { return (int)bt.cts.size(); }
 bool bootstrap_is_sparse(const Bootstrap& bt) { return bt.sparse; }
-void bootstrap_matrix(const Bootstrap& bt, int i, int* level, int* n1, const std::vector<int>** ks, const std::vector<u64*>** plains) {
+void bootstrap_matrix(const Bootstrap& bt, int i, int* level, int* n1, const std::vector<int>** ks, const std::vector<u64*>** plains,
+                      int* rows) {
     LSA_REQUIRE(i >= 0 && i < bootstrap_matrices(bt), "bootstrap: matrix index out of range");
     const int nc = (int)bt.cts.size(), extra = bt.sparse ? 2 : 0;
     const BtMatrix& m = i < nc ? bt.cts[i] : (i < nc + extra ? (i == nc ? bt.p1 : bt.p2) : bt.stc[i - nc - extra]);
@@ -971,6 +1126,7 @@ void bootstrap_matrix(const Bootstrap& bt, int i, int* level, int* n1, const std
     *n1 = m.naive ? 0 : m.n1;
     *ks = &m.ks;
     *plains = &m.plains;
+    if (rows) *rows = m.rows;
 }
 
 }  // namespace lsa

@@ -161,6 +161,16 @@
 #else
 #define LSA_BF_AC ""
 #endif
+#if defined(LSA_KSMAC_WAVES_FP) && LSA_KSMAC_WAVES_FP != 2
+#define LSA_BF_AE " LSA_KSMAC_WAVES_FP=" LSA_BF_STR(LSA_KSMAC_WAVES_FP)
+#else
+#define LSA_BF_AE ""
+#endif
+#if defined(LSA_KSMAC_CHUNK) && LSA_KSMAC_CHUNK != 4
+#define LSA_BF_AF " LSA_KSMAC_CHUNK=" LSA_BF_STR(LSA_KSMAC_CHUNK)
+#else
+#define LSA_BF_AF ""
+#endif
 #ifdef LSA_NTT_DIAG_TW8
 #define LSA_BF_AD " LSA_NTT_DIAG_TW8"
 #else
@@ -180,4 +190,4 @@
 // (leading blank stripped by lsa_build_flags)
 #define LSA_BUILD_FLAGS_TEXT                                                                                              \
     LSA_BF_DIAG LSA_BF_A LSA_BF_B LSA_BF_C LSA_BF_D LSA_BF_E LSA_BF_F LSA_BF_G LSA_BF_H LSA_BF_I LSA_BF_J LSA_BF_K LSA_BF_L \
-        LSA_BF_M LSA_BF_N LSA_BF_O LSA_BF_P LSA_BF_Q LSA_BF_R LSA_BF_S LSA_BF_T LSA_BF_U LSA_BF_V LSA_BF_W LSA_BF_X LSA_BF_Y LSA_BF_Z LSA_BF_AA LSA_BF_AB LSA_BF_AC LSA_BF_AD
+        LSA_BF_M LSA_BF_N LSA_BF_O LSA_BF_P LSA_BF_Q LSA_BF_R LSA_BF_S LSA_BF_T LSA_BF_U LSA_BF_V LSA_BF_W LSA_BF_X LSA_BF_Y LSA_BF_Z LSA_BF_AA LSA_BF_AB LSA_BF_AC LSA_BF_AD LSA_BF_AE LSA_BF_AF

@@ -478,10 +478,20 @@ int lsa_bootstrap_plaintext(lsa_bootstrap b, int matrix, int diag_pos, uint64_t*
         int lv, n1v;
         const std::vector<int>* ks;
         const std::vector<u64*>* pl;
-        bootstrap_matrix(*b->b, matrix, &lv, &n1v, &ks, &pl);
+        int rows = 0;
+        bootstrap_matrix(*b->b, matrix, &lv, &n1v, &ks, &pl, &rows);
         LSA_REQUIRE(diag_pos >= 0 && diag_pos < (int)pl->size(), "diagonal position out of range");
         b->c->use_device();
-        LSA_HIP(hipMemcpy(host_out, (*pl)[diag_pos], (size_t)(lv + 1) * b->c->n * sizeof(u64), hipMemcpyDeviceToHost));
+        LSA_HIP(hipMemcpy(host_out, (*pl)[diag_pos], (size_t)rows * b->c->n * sizeof(u64), hipMemcpyDeviceToHost));
+    });
+}
+int lsa_bootstrap_plaintext_rows(lsa_bootstrap b, int matrix, int* rows) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr && rows != nullptr, "null argument");
+        int lv, n1v;
+        const std::vector<int>* ks;
+        const std::vector<u64*>* pl;
+        bootstrap_matrix(*b->b, matrix, &lv, &n1v, &ks, &pl, rows);
     });
 }
 int lsa_ckks_bootstrap(lsa_context ctx, lsa_bootstrap b, const uint64_t* in, uint64_t* out, int batch, long long sin, long long sout,

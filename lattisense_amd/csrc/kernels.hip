@@ -722,7 +722,6 @@ void launch_mac_plain(Context& c, int terms, const u64* const* ct, const long lo
 // The inner sums of a baby-step / giant-step linear transform in ONE launch: out[g] = sum_b ct[b] * pt[g][b] for every giant
 // step g.  Each baby-step ciphertext is read once for all giant steps (k_mac_plain, one launch per giant step, re-reads all of
 // them every time): nb*polys + terms + ng*polys limb streams instead of terms*(polys + 1) + ng*polys.
-#define LSA_MACM_MAX 8
 struct MacPlainMultiArgs {
     const u64* ct[LSA_MACM_MAX];
     long long sct[LSA_MACM_MAX];
@@ -730,37 +729,60 @@ struct MacPlainMultiArgs {
     u64* out[LSA_MACM_MAX];
     long long so;
     const ModDev* mods;
-    int nb, ng, polys, limbs, logn;
+    int nb, ng, polys, limbs, logn, batch, xcd_map;
     unsigned char mod_of[LSA_MAX_PERIOD];
 };
 
-// grid: x = polys*limbs*(N/2/TPB), y = batch
+// One workgroup = one 512-coefficient piece of one limb of one batch item, BOTH polynomials (they meet the same plaintext
+// words).  The plaintext pieces are the larger half of a workgroup's reads (nb*ng of them against 2*nb ciphertext pieces) and are
+// shared by the whole batch: the batch index varies fastest and, where the piece count allows, the workgroups of one piece
+// are dealt to ONE XCD (consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2), so a piece is
+// fetched from HBM once instead of once per batch item (LSA_MACM_NO_XCD=1: batch-fastest order only).
+template <int POLYS>
 __global__ __launch_bounds__(TPB) void k_mac_plain_multi(MacPlainMultiArgs g) {
     const int chunks = (1 << g.logn) / (2 * TPB);
-    const int row = blockIdx.x / chunks;             // poly * limbs + limb
-    const int limb = row % g.limbs;
-    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    int piece, b;
+    if (g.xcd_map) {
+        const int w = (int)blockIdx.x, slot = w >> 3;
+        b = slot % g.batch;
+        piece = (slot / g.batch) * 8 + (w & 7);
+    } else {
+        b = (int)blockIdx.x % g.batch;
+        piece = (int)blockIdx.x / g.batch;
+    }
+    const int limb = piece / chunks;
+    const int x = ((piece % chunks) * TPB + threadIdx.x) * 2;
     const ModDev m = g.mods[g.mod_of[limb]];
-    const long long b = blockIdx.y;
-    const long long coff = ((long long)row << g.logn) + x, poff = ((long long)limb << g.logn) + x;
-    ulonglong2 c[LSA_MACM_MAX];
+    const long long poff = ((long long)limb << g.logn) + x, pstep = (long long)g.limbs << g.logn;
+    ulonglong2 c[POLYS][LSA_MACM_MAX];
 #pragma unroll
     for (int i = 0; i < LSA_MACM_MAX; i++)
-        if (i < g.nb) c[i] = ld2(g.ct[i] + b * g.sct[i] + coff);
+        if (i < g.nb) {
+#pragma unroll
+            for (int p = 0; p < POLYS; p++) c[p][i] = ld2(g.ct[i] + (long long)b * g.sct[i] + p * pstep + poff);
+        }
     for (int gi = 0; gi < g.ng; gi++) {
-        u64 h0 = 0, l0 = 0, h1 = 0, l1 = 0;   // at most 8 products of < q^2, q < 2^61: below q * 2^64
+        u64 h[POLYS][2], l[POLYS][2];   // at most 8 products of < q^2, q < 2^61: below q * 2^64
+#pragma unroll
+        for (int p = 0; p < POLYS; p++) h[p][0] = h[p][1] = l[p][0] = l[p][1] = 0;
 #pragma unroll
         for (int i = 0; i < LSA_MACM_MAX; i++) {
             if (i < g.nb && g.pt[gi][i]) {
                 const ulonglong2 w = ld2(g.pt[gi][i] + poff);
-                mac128(h0, l0, c[i].x, w.x);
-                mac128(h1, l1, c[i].y, w.y);
+#pragma unroll
+                for (int p = 0; p < POLYS; p++) {
+                    mac128(h[p][0], l[p][0], c[p][i].x, w.x);
+                    mac128(h[p][1], l[p][1], c[p][i].y, w.y);
+                }
             }
         }
-        u64 r0 = csub(mont_redc_lazy(h0, l0, m.q, m.qinv), m.q), r1 = csub(mont_redc_lazy(h1, l1, m.q, m.qinv), m.q);
-        r0 = mont_mul(r0, m.r2, m.q, m.qinv);            // sum * R^-1 -> sum
-        r1 = mont_mul(r1, m.r2, m.q, m.qinv);
-        st2(g.out[gi] + b * g.so + coff, r0, r1);
+#pragma unroll
+        for (int p = 0; p < POLYS; p++) {
+            u64 r0 = csub(mont_redc_lazy(h[p][0], l[p][0], m.q, m.qinv), m.q), r1 = csub(mont_redc_lazy(h[p][1], l[p][1], m.q, m.qinv), m.q);
+            r0 = mont_mul(r0, m.r2, m.q, m.qinv);            // sum * R^-1 -> sum
+            r1 = mont_mul(r1, m.r2, m.q, m.qinv);
+            st2(g.out[gi] + (long long)b * g.so + p * pstep + poff, r0, r1);
+        }
     }
 }
 
@@ -791,8 +813,16 @@ void launch_mac_plain_multi(Context& c, int nb, const u64* const* ct, const long
     g.logn = c.logn;
     int period;
     fill_rowmap(g.mod_of, period, rm, c.nmod);
-    ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * limbs * batch * ((double)nb * polys + (double)terms * polys + (double)ng * polys), s);
-    hipLaunchKernelGGL(k_mac_plain_multi, ew_grid(c, polys * limbs, batch), dim3(TPB), 0, s, g);
+    // algorithmic bytes: every ciphertext piece read once, every plaintext ONCE per launch (shared by the batch), the sums written
+    ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * limbs * ((double)batch * polys * (nb + ng) + (double)terms), s);
+    LSA_REQUIRE(polys == 1 || polys == 2, "mac: one or two polynomials per ciphertext");
+    const int pieces = limbs * (c.n / (2 * TPB));
+    g.batch = batch;
+    g.xcd_map = (pieces % 8 == 0 && !std::getenv("LSA_MACM_NO_XCD")) ? 1 : 0;
+    LSA_REQUIRE(c.n >= 2 * TPB, "ring degree too small for the elementwise kernels (need N >= 512)");
+    const dim3 grid((unsigned)(pieces * batch));
+    if (polys == 2) hipLaunchKernelGGL(k_mac_plain_multi<2>, grid, dim3(TPB), 0, s, g);
+    else hipLaunchKernelGGL(k_mac_plain_multi<1>, grid, dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
 
@@ -1448,6 +1478,93 @@ void launch_permute_ntt(Context& c, const u32* perm, const u64* in, long long si
     g.period = 1;
     ProfScope ps(c, PROF_ELEMWISE, 16.0 * c.n * rows * batch, s);
     hipLaunchKernelGGL(k_permute, ew_grid(c, rows, batch), dim3(TPB), 0, s, g);
+    LSA_HIP(hipGetLastError());
+}
+
+// Extended (Q_level u P) ciphertexts, the operands of double-hoisted linear transforms: a rotation WITHOUT its division by P.
+//   out[h][tl][i] (+)= acc[h][tl][perm[i]] + (tl < L and h < base_polys ? P * base[h][tl][perm[i]] mod q_tl : 0)
+// acc = the gadget product [2][T][N] (null: zero), base = the ciphertext [2][L][N] whose c0 (base_polys = 1) or both
+// polynomials (2: the plain lift of a ciphertext) enter times P; perm null = identity.
+struct PermExtArgs {
+    const u32* perm;
+    const u64* acc;
+    const u64* base;
+    const u64* pm;   // [L] P mod q_j, Montgomery form
+    u64* out;
+    long long sacc, sbase, sout;
+    const ModDev* mods;
+    int L, T, logn, accumulate, base_polys;
+    unsigned char mod_of[LSA_MAX_PERIOD];   // [T]
+};
+
+__global__ __launch_bounds__(TPB) void k_permute_ext(PermExtArgs g) {
+    const int chunks = (1 << g.logn) / (2 * TPB);
+    const int row = blockIdx.x / chunks;
+    const int h = row / g.T, tl = row - h * g.T;
+    const int x = ((blockIdx.x % chunks) * TPB + threadIdx.x) * 2;
+    const long long b = blockIdx.y;
+    const ModDev m = g.mods[g.mod_of[tl]];
+    unsigned i0 = (unsigned)x, i1 = (unsigned)x + 1;
+    if (g.perm) {
+        const uint2 p = *reinterpret_cast<const uint2*>(g.perm + x);
+        i0 = p.x;
+        i1 = p.y;
+    }
+    u64 r0 = 0, r1 = 0;
+    if (g.acc) {
+        const u64* in = g.acc + b * g.sacc + ((long long)row << g.logn);
+        r0 = in[i0];
+        r1 = in[i1];
+    }
+    if (tl < g.L && h < g.base_polys) {
+        const u64* bs = g.base + b * g.sbase + ((long long)(h * g.L + tl) << g.logn);
+        const u64 k = g.pm[tl];
+        r0 = add_mod(r0, mont_mul(bs[i0], k, m.q, m.qinv), m.q);
+        r1 = add_mod(r1, mont_mul(bs[i1], k, m.q, m.qinv), m.q);
+    }
+    u64* o = g.out + b * g.sout + ((long long)row << g.logn) + x;
+    if (g.accumulate) {
+        const ulonglong2 v = ld2(o);
+        r0 = add_mod(r0, v.x, m.q);
+        r1 = add_mod(r1, v.y, m.q);
+    }
+    st2(o, r0, r1);
+}
+
+void launch_permute_ext(Context& c, int level, const u32* perm, const u64* acc, long long sacc, const u64* base, long long sbase,
+                        int base_polys, u64* out, long long sout, bool accumulate, int batch, hipStream_t s) {
+    if (batch <= 0) return;
+    const int L = level + 1, T = L + c.np;
+    LSA_REQUIRE(T <= LSA_MAX_PERIOD, "extended ciphertext: too many limbs");
+    LSA_REQUIRE(base_polys == 0 || base, "extended ciphertext: base polynomial missing");
+    PermExtArgs g{};
+    g.perm = perm;
+    g.acc = acc;
+    g.base = base;
+    g.out = out;
+    g.sacc = sacc;
+    g.sbase = sbase;
+    g.sout = sout;
+    g.mods = c.d_mods;
+    g.L = L;
+    g.T = T;
+    g.logn = c.logn;
+    g.accumulate = accumulate ? 1 : 0;
+    g.base_polys = base_polys;
+    std::vector<int> mods(L);
+    std::vector<u64> pm(L);
+    for (int j = 0; j < L; j++) {
+        mods[j] = j;
+        const u64 q = c.T.mod[j];
+        u64 pr = 1;
+        for (int l = 0; l < c.np; l++) pr = mul_mod_host(pr, c.T.mod[c.p_mod(l)] % q, q);
+        pm[j] = pr;
+    }
+    g.pm = c.const_vec("pmodq" + std::to_string(L), mods, pm);
+    for (int tl = 0; tl < T; tl++) g.mod_of[tl] = (unsigned char)(tl < L ? tl : c.p_mod(tl - L));
+    const double streams = (acc ? 1.0 : 0.0) * 2 * T + (double)base_polys * L + (accumulate ? 2.0 : 1.0) * 2 * T;
+    ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * streams * batch, s);
+    hipLaunchKernelGGL(k_permute_ext, ew_grid(c, 2 * T, batch), dim3(TPB), 0, s, g);
     LSA_HIP(hipGetLastError());
 }
 

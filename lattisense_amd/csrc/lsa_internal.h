@@ -232,6 +232,7 @@ void launch_muladd(Context& c, EwOp op, const u64* a, const u64* b, const u64* a
                    long long sa, long long sb, long long so, int rows, const RowMap& rm, hipStream_t s);
 // out[p][j] = (partial[p][j]) + sum_{i<terms} ct_i[p][j] * pt_i[j], one launch; each operand is (base, batch stride)
 #define LSA_MAC_MAX_TERMS 16
+#define LSA_MACM_MAX 8   // baby and giant steps per k_mac_plain_multi launch
 void launch_mac_plain(Context& c, int terms, const u64* const* ct, const long long* sct, const u64* const* pt,
                       const long long* spt, const u64* partial, long long spartial, u64* out, long long so, int batch,
                       int polys, int limbs, const RowMap& rm, hipStream_t s);
@@ -274,6 +275,9 @@ void launch_permute_ntt(Context& c, const u32* perm, const u64* in, long long si
                         int batch, hipStream_t s);
 void launch_permute_coeff(Context& c, const u32* perm, const u64* in, long long sin, u64* out, long long sout, int rows,
                           const RowMap& rm, int batch, hipStream_t s);
+// extended (Q_level u P) ciphertext: out (+)= perm(acc + P * base) -- a rotation without its division by P (k_permute_ext)
+void launch_permute_ext(Context& c, int level, const u32* perm, const u64* acc, long long sacc, const u64* base, long long sbase,
+                        int base_polys, u64* out, long long sout, bool accumulate, int batch, hipStream_t s);
 // strided row copy: out[b][r] = in[b][src_row[r]]
 void launch_copy_rows(Context& c, const u64* in, long long sin, u64* out, long long sout, int rows, const int* src_row,
                       int batch, hipStream_t s);
@@ -310,7 +314,8 @@ const std::vector<u64>& bootstrap_galois(const Bootstrap& bt);
 const std::vector<double>& bootstrap_chebyshev(const Bootstrap& bt);
 int bootstrap_matrices(const Bootstrap& bt);
 int bootstrap_cts_matrices(const Bootstrap& bt);
-void bootstrap_matrix(const Bootstrap& bt, int i, int* level, int* n1, const std::vector<int>** ks, const std::vector<u64*>** plains);
+void bootstrap_matrix(const Bootstrap& bt, int i, int* level, int* n1, const std::vector<int>** ks, const std::vector<u64*>** plains,
+                      int* rows = nullptr);
 void bootstrap_run(Bootstrap& bt, const u64* in, long long sin, u64* out, long long sout, int batch, const Key& rlk,
                    const std::map<u64, const Key*>& glk, const Key* swk_dts, const Key* swk_std, hipStream_t s);
 

@@ -119,29 +119,61 @@ static void ks_decompose(Context& c, int level, const u64* cx, long long scx, in
     }
 }
 
+struct KsWorkspace {   // where ks_decompose / ks_mac / ks_moddown keep their intermediates inside one tile's workspace
+    u64 *cxi, *ext, *acc, *conv;
+    long long s_ext, s_acc, s_conv;
+};
+static KsWorkspace ks_layout(const Context& c, int level, int nb, u64* ws) {
+    const long long N = c.n;
+    const int L = level + 1, T = L + c.np, beta = ceil_div(L, c.np);
+    KsWorkspace w;
+    w.cxi = ws;
+    w.ext = w.cxi + (size_t)nb * L * N;
+    w.acc = w.ext + (size_t)nb * beta * T * N;
+    w.conv = w.acc + (size_t)nb * 2 * T * N;
+    w.s_ext = (long long)beta * T * N;
+    w.s_acc = 2LL * T * N;
+    w.s_conv = 2LL * L * N;
+    return w;
+}
+
+// step 4 of a key switch on the digits that ks_decompose left in the workspace: the gadget inner product with the key (both
+// halves) -> w.acc, [2][L+k][N] over Q_level u P, NTT domain; fused with the extension transform's second pass when
+// ks_decompose stopped after the first one
+static void ks_mac(Context& c, int level, const u64* cx, long long scx, const Key& key, int nb, u64* ws, hipStream_t s,
+                   bool ext_first_pass_only) {
+    const KsWorkspace w = ks_layout(c, level, nb, ws);
+    if (ext_first_pass_only) {
+        const int eng = ks_fused_engines(c);
+        LSA_REQUIRE(launch_ntt_ksmac(c, level, cx, scx, w.ext, w.s_ext, key, w.acc, w.s_acc, nb, s, eng), "fused key MAC: shape not covered");
+        for (int e = 0; e < 2; e++)
+            if (!((eng >> e) & 1)) launch_ks_mac(c, level, cx, scx, w.ext, w.s_ext, key, w.acc, w.s_acc, nb, s, e);
+    } else {
+        launch_ks_mac(c, level, cx, scx, w.ext, w.s_ext, key, w.acc, w.s_acc, nb, s);
+    }
+}
+
+static void ks_moddown(Context& c, int level, u64* acc, long long s_acc, u64* conv, u64* p, long long sp, const u64* base,
+                       long long sbase, int base_rpp, int base_polys, int nb, hipStream_t s, const KsRescale* rs, bool coeff_out);
+
 // steps 4-5 of a key switch on the digits that ks_decompose left in the workspace: they depend on the key, the decomposition
 // does not -- rotations of ONE ciphertext by several Galois elements share it ("hoisting"; with the automorphism applied
 // after the switch, as here, every rotation's residues are the same as if it had been computed on its own)
 static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
                       const KsRescale* rs, bool coeff_out, bool ext_first_pass_only) {
+    const KsWorkspace w = ks_layout(c, level, nb, ws);
+    ks_mac(c, level, cx, scx, key, nb, ws, s, ext_first_pass_only);
+    ks_moddown(c, level, w.acc, w.s_acc, w.conv, p, sp, base, sbase, base_rpp, base_polys, nb, s, rs, coeff_out);
+}
+
+// step 5, the division by P of a polynomial pair over Q_level u P (acc: [2][L+k][N] per batch item, NTT domain; its P rows --
+// and, for the merged rescale, its last Q row -- are transformed in place), conv: 2L rows of scratch per batch item
+static void ks_moddown(Context& c, int level, u64* acc, long long s_acc, u64* conv, u64* p, long long sp, const u64* base,
+                       long long sbase, int base_rpp, int base_polys, int nb, hipStream_t s, const KsRescale* rs, bool coeff_out) {
     const long long N = c.n;
-    const int L = level + 1, np = c.np, T = L + np, beta = ceil_div(L, np);
-    u64* cxi = ws;
-    u64* ext = cxi + (size_t)nb * L * N;
-    u64* acc = ext + (size_t)nb * beta * T * N;
-    u64* conv = acc + (size_t)nb * 2 * T * N;
-    const long long s_ext = (long long)beta * T * N, s_acc = 2LL * T * N, s_conv = 2LL * L * N;
-    // 4. gadget inner product with the key (both halves); fused with the extension transform's second pass when ks_decompose
-    //    stopped after the first one
-    if (ext_first_pass_only) {
-        const int eng = ks_fused_engines(c);
-        LSA_REQUIRE(launch_ntt_ksmac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s, eng), "fused key MAC: shape not covered");
-        for (int e = 0; e < 2; e++)
-            if (!((eng >> e) & 1)) launch_ks_mac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s, e);
-    } else {
-        launch_ks_mac(c, level, cx, scx, ext, s_ext, key, acc, s_acc, nb, s);
-    }
+    const int L = level + 1, np = c.np, T = L + np;
+    const long long s_conv = 2LL * L * N;
     // 5. ModDown: P-part out of NTT, centred exact conversion P -> Q, back to NTT, (accQ - conv) * P^-1 (+ base).
     //    coeff_out (BFV: the result is wanted in the coefficient domain and `base` is given there): every row of acc leaves
     //    the NTT domain once and the tail runs on coefficients -- INTT((acc - NTT(conv)) * P^-1) == (INTT(acc) - conv) * P^-1
@@ -399,6 +431,57 @@ void ckks_rotate_many(Context& c, int level, const u64* in, int n_rot, const u64
             ks_finish(c, level, ct + (long long)L * N, sin, *glk[i], p, sp, ct, sin, L, 1, nb, ws, st, nullptr);
             launch_permute_ntt(c, perms[i], p, sp, outs[i] + (size_t)b0 * sout, sout, 2 * L, nb, st);
         }
+    });
+}
+
+// ---- extended ciphertexts: (c0, c1) times P over Q_level u P, [2][L+k][N] in the NTT domain -- what a key switch holds before
+// its division by P.  Sums of them are exact, so a baby-step / giant-step linear transform divides once per giant step and
+// once at the end instead of once per rotation ("double hoisting": Lattigo v4 ckks/linear_transform.go
+// MultiplyByDiagMatrixBSGS over rlwe GadgetProductNoModDown / ModDownQPtoQNTT; bootstrap.hip, Eval::linear_transform).
+void ckks_lift_ext(Context& c, int level, const u64* in, u64* out, int batch, long long sin, long long sout, hipStream_t s) {
+    launch_permute_ext(c, level, nullptr, nullptr, 0, in, sin, 2, out, sout, false, batch, s);
+}
+
+// outs[i] = automorphism_g[i]( (P c0 + ks0, ks1) ), ks = gadget product of c1 with glk[i]; one decomposition for all
+void ckks_rotate_many_ext(Context& c, int level, const u64* in, int n_rot, const u64* g, const Key* const* glk, u64* const* outs,
+                          int batch, long long sin, long long sout, hipStream_t s) {
+    if (n_rot <= 0) return;
+    const long long N = c.n;
+    const int L = level + 1;
+    std::vector<const u32*> perms(n_rot);
+    for (int i = 0; i < n_rot; i++) perms[i] = c.ntt_perm(g[i]);
+    for_tiles(c, ks_ws_rows(c, level), batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
+        const u64* ct = in + (size_t)b0 * sin;
+        const KsWorkspace w = ks_layout(c, level, nb, ws);
+        ks_decompose(c, level, ct + (long long)L * N, sin, nb, ws, st);
+        for (int i = 0; i < n_rot; i++) {
+            ks_mac(c, level, ct + (long long)L * N, sin, *glk[i], nb, ws, st, false);
+            launch_permute_ext(c, level, perms[i], w.acc, w.s_acc, ct, sin, 1, outs[i] + (size_t)b0 * sout, sout, false, nb, st);
+        }
+    });
+}
+
+// out (+)= automorphism_g( (P c0 + ks0, ks1) ): one rotation without its division by P, optionally added to `out`
+void ckks_rotate_ext(Context& c, int level, const u64* in, u64 g, const Key& glk, u64* out, bool accumulate, int batch,
+                     long long sin, long long sout, hipStream_t s) {
+    const long long N = c.n;
+    const int L = level + 1;
+    const u32* perm = c.ntt_perm(g);
+    const bool fuse = ks_fuse_mac(c, level, glk);
+    for_tiles(c, ks_ws_rows(c, level), batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
+        const u64* ct = in + (size_t)b0 * sin;
+        const KsWorkspace w = ks_layout(c, level, nb, ws);
+        ks_decompose(c, level, ct + (long long)L * N, sin, nb, ws, st, nullptr, 0, !fuse);
+        ks_mac(c, level, ct + (long long)L * N, sin, glk, nb, ws, st, fuse);
+        launch_permute_ext(c, level, perm, w.acc, w.s_acc, ct, sin, 1, out + (size_t)b0 * sout, sout, accumulate, nb, st);
+    });
+}
+
+// the rounded division by P: extended ciphertext -> ciphertext [2][L][N].  `in` is clobbered (its P rows leave the NTT domain).
+void ckks_moddown_ext(Context& c, int level, u64* in, u64* out, int batch, long long sin, long long sout, hipStream_t s) {
+    const int L = level + 1;
+    for_tiles(c, 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
+        ks_moddown(c, level, in + (size_t)b0 * sin, sin, ws, out + (size_t)b0 * sout, sout, nullptr, 0, 0, 0, nb, st, nullptr, false);
     });
 }
 

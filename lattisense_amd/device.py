@@ -229,6 +229,13 @@ class BootstrapPlan:
         g = (ctypes.c_uint64 * ng.value)()
         check(lib().lsa_bootstrap_galois_elements(self.h, g, ng.value))
         self.galois_elements = [int(x) for x in g]
+        # double hoisting (the default): baby-step / giant-step matrices carry plaintext rows for the special primes too
+        self.double_hoist = False
+        for i in range(self.n_matrices):
+            lvl, rows = ctypes.c_int(), ctypes.c_int()
+            check(lib().lsa_bootstrap_matrix_info(self.h, i, ctypes.byref(lvl), None, None, None, 0))
+            check(lib().lsa_bootstrap_plaintext_rows(self.h, i, ctypes.byref(rows)))
+            self.double_hoist = self.double_hoist or rows.value > lvl.value + 1
 
     def close(self):
         if self.h:
@@ -248,14 +255,17 @@ class BootstrapPlan:
         return np.array(c[:], dtype=np.float64), (np.array(a[: na.value], dtype=np.float64) if na.value else None)
 
     def matrix(self, index):
-        """(level, n1 (0: no baby-step/giant-step), diagonal indices, {k: plaintext [level+1][N]})"""
+        """(level, n1 (0: no baby-step/giant-step), diagonal indices, {k: plaintext [rows][N]}); rows = level+1, or level+1+k
+        (residues at the special primes too) for a baby-step / giant-step matrix of a double-hoisting plan"""
         lv, n1, nd = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(lib().lsa_bootstrap_matrix_info(self.h, index, ctypes.byref(lv), ctypes.byref(n1), ctypes.byref(nd), None, 0))
         ks = (ctypes.c_int * nd.value)()
         check(lib().lsa_bootstrap_matrix_info(self.h, index, None, None, None, ks, nd.value))
         plains = {}
+        rows = ctypes.c_int()
+        check(lib().lsa_bootstrap_plaintext_rows(self.h, index, ctypes.byref(rows)))
         for i, k in enumerate(ks):
-            pt = np.empty((lv.value + 1, self.ctx.n), dtype=np.uint64)
+            pt = np.empty((rows.value, self.ctx.n), dtype=np.uint64)
             check(lib().lsa_bootstrap_plaintext(self.h, index, i, pt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
             plains[int(k)] = pt
         return lv.value, n1.value, [int(k) for k in ks], plains
@@ -275,3 +285,14 @@ class BootstrapPlan:
         keys = [("cts", i) for i in range(self.n_cts)] + ([("p1",), ("p2",)] if self.sparse else [])
         keys += [("stc", i) for i in range(self.n_matrices - len(keys))]
         return {k: self.matrix(i)[3] for i, k in enumerate(keys)}
+
+    def oracle_levels(self):
+        """level of every matrix, keyed like oracle_plains()"""
+        keys = [("cts", i) for i in range(self.n_cts)] + ([("p1",), ("p2",)] if self.sparse else [])
+        keys += [("stc", i) for i in range(self.n_matrices - len(keys))]
+        out = {}
+        for i, k in enumerate(keys):
+            lv = ctypes.c_int()
+            check(lib().lsa_bootstrap_matrix_info(self.h, i, ctypes.byref(lv), None, None, None, 0))
+            out[k] = lv.value
+        return out

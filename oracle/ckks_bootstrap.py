@@ -28,6 +28,9 @@ import numpy as np
 from .client import galois_element_for_col_rotation, galois_element_for_row_rotation
 
 Ct = namedtuple("Ct", "data level scale")   # data: [2][level+1][N] NTT-domain residues
+# a ciphertext times P over Q_level u P (rows: q_0..q_level, then the special primes), NTT domain: what a key switch yields
+# before its division by P.  Sums of such stay exact; ONE rounded division (moddown) per sum instead of one per term.
+ExtCt = namedtuple("ExtCt", "data level scale")
 
 
 # ------------------------------------------------------------------------------------------------ evaluator
@@ -83,6 +86,63 @@ class Evaluator:
         g = galois_element_for_col_rotation(r, self.n)
         self.counts["rotate"] += 1
         return Ct(self.o.ckks_rotate(a.level, a.data, g, self._key(g), self.klvl), a.level, a.scale)
+
+    # --- extended (Q u P) ciphertexts: the operands of the double-hoisted linear transform
+    # (Lattigo v4 ckks/linear_transform.go MultiplyByDiagMatrixBSGS, rlwe GadgetProductNoModDown / ModDownQPtoQNTT)
+    def _mi(self, level, tl):
+        """modulus index of row tl of an extended polynomial at `level`"""
+        return tl if tl <= level else self.o.nq + (tl - level - 1)
+
+    def lift_ext(self, a):
+        """(P c0, P c1) on the Q rows, zero on the P rows: the same ciphertext, times P"""
+        L, T = a.level + 1, a.level + 1 + self.o.np_
+        d = np.zeros((2, T, self.n), dtype=np.uint64)
+        for j in range(L):
+            pm = 1
+            for pp in self.o.p:
+                pm = pm * (pp % self.q(j)) % self.q(j)
+            for pl in range(2):
+                d[pl, j] = self.o.vec("mul", j, a.data[pl, j], self._const(pm, j))
+        return ExtCt(d, a.level, a.scale)
+
+    def rotate_ext(self, a, r):
+        """rotation WITHOUT the division by P: automorphism of (P c0 + ks0, ks1), ks = gadget product of c1 with the key"""
+        r %= self.n // 2
+        if r == 0:
+            return self.lift_ext(a)
+        g = galois_element_for_col_rotation(r, self.n)
+        self.counts["rotate"] += 1
+        L = a.level + 1
+        acc = self.o.gadget_product(a.level, a.data[1], self._key(g), self.klvl)
+        c0p = self.lift_ext(a).data[0]
+        for j in range(L):
+            acc[0, j] = self.o.vec("add", j, acc[0, j], c0p[j])
+        out = np.stack([np.stack([self.o.automorph_ntt(g, acc[pl, tl]) for tl in range(acc.shape[1])]) for pl in range(2)])
+        return ExtCt(out, a.level, a.scale)
+
+    def mul_plain_ext(self, a, pt, pt_scale):
+        """extended ciphertext times an NTT-domain plaintext over the same moduli [level+1+np][N]"""
+        self.counts["mul_plain"] += 1
+        T = a.data.shape[1]
+        d = np.stack([np.stack([self.o.vec("mul", self._mi(a.level, tl), a.data[pl, tl], pt[tl]) for tl in range(T)]) for pl in range(2)])
+        return ExtCt(d, a.level, a.scale * pt_scale)
+
+    def add_ext(self, a, b):
+        assert a.level == b.level and abs(a.scale / b.scale - 1) < 1e-9
+        T = a.data.shape[1]
+        d = np.stack([np.stack([self.o.vec("add", self._mi(a.level, tl), a.data[pl, tl], b.data[pl, tl]) for tl in range(T)]) for pl in range(2)])
+        return ExtCt(d, a.level, a.scale)
+
+    def moddown(self, a):
+        """the rounded division by P that ends a key switch, on a sum of extended ciphertexts"""
+        return Ct(self.o.moddown(a.level, a.data), a.level, a.scale)
+
+    def encode_ext(self, z, level, scale):
+        """plaintext over Q_level u P: the same integer polynomial reduced at the special primes too"""
+        m = self.c.ckks_encode_coeffs(z, scale)
+        T = level + 1 + self.o.np_
+        return np.stack([self.o.ntt(self._mi(level, tl), np.array([int(x) % self.o.mod[self._mi(level, tl)] for x in m], dtype=np.uint64))
+                         for tl in range(T)])
 
     def conj(self, a):
         g = galois_element_for_row_rotation(self.n)
@@ -234,12 +294,15 @@ def rotations_of(diags, n_slots, ratio=2.0):
     return sorted({r for r in giants + babies if r})
 
 
-def linear_transform(ev, ct, diags, ratio=2.0, plains=None, rescale=True, n_slots=None):
+def linear_transform(ev, ct, diags, ratio=2.0, plains=None, rescale=True, n_slots=None, double_hoist=True):
     """ct <- M ct for M in diagonal form; the diagonals are encoded at the scale of the ciphertext's top prime, so the single
     rescale at the end leaves the scale unchanged.  Consumes one level.  Fewer than three diagonals: one rotation each;
     otherwise baby-step / giant-step with the planner's split:
-        M x = sum_g rot_g( sum_b rot_{-g}(d_{g+b}) . rot_b(x) )."""
-    # `plains`: {k: NTT-domain plaintext [level+1][N]} replaces this module's own encoding of (rot_{-g} of) diagonal k --
+        M x = sum_g rot_g( sum_b rot_{-g}(d_{g+b}) . rot_b(x) ).
+    double_hoist (Lattigo's MultiplyByDiagMatrixBSGS): the baby-step rotations stay over Q u P (no division by P), the
+    plaintexts are encoded over Q u P too, each giant step's inner sum is divided by P once, rotated without division, and the
+    sum over the giant steps is divided once more: (giant steps + 1) rounded divisions instead of one per rotation."""
+    # `plains`: {k: NTT-domain plaintext [level+1 (+np)][N]} replaces this module's own encoding of (rot_{-g} of) diagonal k --
     # the parity tests pass the device library's plaintexts so that both sides multiply by the same integers
     # n_slots: period of the diagonals (sparse packing: shorter than N/2; they are tiled over the N/2 slots when encoded)
     n = ev.n // 2
@@ -259,6 +322,22 @@ def linear_transform(ev, ct, diags, ratio=2.0, plains=None, rescale=True, n_slot
     by_giant = {}
     for k in ks:
         by_giant.setdefault((k // n1) * n1, []).append(k)
+    if double_hoist:
+        for g, klist in sorted(by_giant.items()):
+            inner = None
+            for k in klist:
+                b = k - g
+                if b not in babies:
+                    babies[b] = ev.rotate_ext(ct, b)
+                pt = plains[k] if plains is not None else ev.encode_ext(tile(np.roll(diags[k], g)), ct.level, pt_scale)
+                assert len(pt) == ct.level + 1 + ev.o.np_, "double hoisting: plaintexts must cover the special primes"
+                term = ev.mul_plain_ext(babies[b], pt, pt_scale)
+                inner = term if inner is None else ev.add_ext(inner, term)
+            if g % n:
+                inner = ev.rotate_ext(ev.moddown(inner), g)
+            acc = inner if acc is None else ev.add_ext(acc, inner)
+        acc = ev.moddown(acc)
+        return ev.rescale(acc) if rescale else acc
     for g, klist in sorted(by_giant.items()):
         inner = None
         for k in klist:
@@ -382,10 +461,11 @@ def eval_mod(ev, u, K, double_angle, coeffs=None, asin=None, sine_deg=30):
 # ------------------------------------------------------------------------------------------------ bootstrap
 class Bootstrapper:
     def __init__(self, ev, cts_depth=4, stc_depth=3, K=16, double_angle=3, message_ratio=256.0, out_scale=None,
-                 plains=None, coeffs=None, sine_deg=30, arcsine_deg=0, asin=None):
+                 plains=None, coeffs=None, sine_deg=30, arcsine_deg=0, asin=None, double_hoist=True):
         """plains: {("cts"|"stc", matrix index): {k: plaintext}}, coeffs (Chebyshev coefficients) and asin (arcsine monomial
         coefficients) override this module's own floating-point constants with another implementation's (see linear_transform)."""
         self.ev = ev
+        self.double_hoist = double_hoist
         self.plains, self.coeffs = plains, coeffs
         self.sine_deg, self.arcsine_deg = sine_deg, arcsine_deg
         self.cheb_depth = max(1, int(sine_deg).bit_length())               # ceil(log2(sine_deg + 1))
@@ -418,7 +498,8 @@ class Bootstrapper:
             n1 = bsgs_split(ks, n, 2.0) if len(ks) >= 3 else 0
             for k in ks:
                 g = (k // n1) * n1 if n1 else 0
-                out[k] = ev.encode(np.roll(diags[k], g), level, float(ev.q(level)))
+                enc = ev.encode_ext if (self.double_hoist and n1) else ev.encode
+                out[k] = enc(np.roll(diags[k], g), level, float(ev.q(level)))
             return out
 
         plains = {}
@@ -490,7 +571,7 @@ class Bootstrapper:
             x = self.key_switch(x, swk_std, top_level)
         # 3. CoeffsToSlots -> packed coefficients t / (2K) in bit-reversed order
         for i, m in enumerate(self.cts):
-            x = linear_transform(ev, x, m, plains=self.plains[("cts", i)] if self.plains else None)
+            x = linear_transform(ev, x, m, plains=self.plains[("cts", i)] if self.plains else None, double_hoist=self.double_hoist)
         xc = ev.conj(x)
         u_re = ev.add(x, xc)                                   # Re(t)/K
         u_im = ev.mul_by_i(ev.sub(x, xc), -1)                  # Im(t)/K
@@ -509,7 +590,7 @@ class Bootstrapper:
             stc[0] = {k: d * kappa for k, d in stc[0].items()}
             natural = self.out_scale
         for i, m in enumerate(stc):
-            y = linear_transform(ev, y, m, plains=self.plains[("stc", i)] if self.plains else None)
+            y = linear_transform(ev, y, m, plains=self.plains[("stc", i)] if self.plains else None, double_hoist=self.double_hoist)
         return Ct(y.data, y.level, natural)
 
 
@@ -525,9 +606,10 @@ class SparseBootstrapper(Bootstrapper):
         (bootstrap_params.py:233, :121-133): t[k] = y[k] + i y[k+slots]."""
 
     def __init__(self, ev, log_slots, cts_depth=4, stc_depth=3, K=16, double_angle=3, message_ratio=256.0, out_scale=None,
-                 plains=None, coeffs=None, sine_deg=30, arcsine_deg=0, asin=None):
+                 plains=None, coeffs=None, sine_deg=30, arcsine_deg=0, asin=None, double_hoist=True):
         """plains keys: ("cts", i) for the leading matrices, ("p1",), ("p2",), ("stc", i)"""
         self.ev = ev
+        self.double_hoist = double_hoist
         self.plains, self.coeffs = plains, coeffs
         self.sine_deg, self.arcsine_deg = sine_deg, arcsine_deg
         self.cheb_depth = max(1, int(sine_deg).bit_length())
@@ -594,9 +676,9 @@ class SparseBootstrapper(Bootstrapper):
             x = ev.add(x, ev.rotate(x, 1 << i))
         pl = self.plains or {}
         for i, m in enumerate(self.cts):
-            x = linear_transform(ev, x, m, n_slots=ns, plains=pl.get(("cts", i)))
-        a = linear_transform(ev, x, self.p1, rescale=False, n_slots=2 * ns, plains=pl.get(("p1",)))
-        b = linear_transform(ev, ev.conj(x), self.p2, rescale=False, n_slots=2 * ns, plains=pl.get(("p2",)))
+            x = linear_transform(ev, x, m, n_slots=ns, plains=pl.get(("cts", i)), double_hoist=self.double_hoist)
+        a = linear_transform(ev, x, self.p1, rescale=False, n_slots=2 * ns, plains=pl.get(("p1",)), double_hoist=self.double_hoist)
+        b = linear_transform(ev, ev.conj(x), self.p2, rescale=False, n_slots=2 * ns, plains=pl.get(("p2",)), double_hoist=self.double_hoist)
         u = ev.rescale(ev.add(a, b))                                    # [Re(t)/K | Im(t)/K], period 2*slots
         y = eval_mod(ev, u, self.K, self.r, self.coeffs, self.asin, self.sine_deg)
         natural = y.scale * 2 * np.pi * d1 / q0
@@ -605,7 +687,7 @@ class SparseBootstrapper(Bootstrapper):
             kappa = self.out_scale / natural
             stc[0] = {k: d * kappa for k, d in stc[0].items()}
             natural = self.out_scale
-        y = linear_transform(ev, y, stc[0], n_slots=2 * ns, plains=pl.get(("stc", 0)))
+        y = linear_transform(ev, y, stc[0], n_slots=2 * ns, plains=pl.get(("stc", 0)), double_hoist=self.double_hoist)
         for i, m in enumerate(stc[1:], 1):
-            y = linear_transform(ev, y, m, n_slots=ns, plains=pl.get(("stc", i)))
+            y = linear_transform(ev, y, m, n_slots=ns, plains=pl.get(("stc", i)), double_hoist=self.double_hoist)
         return Ct(y.data, y.level, natural)

@@ -344,8 +344,9 @@ void ora_automorph_coeff(const ora_ctx* c, int mi, u64 g, const u64* a, u64* r) 
 /* ------------------------------------------------------------------ hybrid key-switch
  * Lattigo rlwe GadgetProduct (DecomposeSingleNTT per digit, MAC with the gadget ciphertexts)
  * followed by BasisExtender.ModDownQPtoQNTT.  digit d = Q-limbs [d*np, min((d+1)*np, L)). */
-void ora_keyswitch(const ora_ctx* c, int lvl, const u64* cx, const u64* key, int klvl,
-                   u64* out0, u64* out1) {
+/* the gadget product alone: acc0, acc1 = [L + np][n] over Q_lvl u P, NTT domain, NOT divided by P (Lattigo
+ * rlwe GadgetProductNoModDown; the operand of the double-hoisted linear transform, ckks MultiplyByDiagMatrixBSGS) */
+void ora_gadget_product(const ora_ctx* c, int lvl, const u64* cx, const u64* key, int klvl, u64* acc0, u64* acc1) {
     int n = c->n, L = lvl + 1, np = c->np, nq = c->nq;
     int beta = (L + np - 1) / np;
     int kcomp = klvl + 1 + np; /* limbs per key polynomial */
@@ -353,8 +354,8 @@ void ora_keyswitch(const ora_ctx* c, int lvl, const u64* cx, const u64* key, int
     u64* cxi = (u64*)malloc(sizeof(u64) * L * n);
     memcpy(cxi, cx, sizeof(u64) * L * n);
     for (int i = 0; i < L; i++) ora_intt(c, i, cxi + (size_t)i * n);
-    u64* acc0 = (u64*)calloc((size_t)T * n, sizeof(u64));
-    u64* acc1 = (u64*)calloc((size_t)T * n, sizeof(u64));
+    memset(acc0, 0, sizeof(u64) * (size_t)T * n);
+    memset(acc1, 0, sizeof(u64) * (size_t)T * n);
     u64* ext = (u64*)malloc(sizeof(u64) * n);
     for (int d = 0; d < beta; d++) {
         int d0 = d * np, d1 = d0 + np < L ? d0 + np : L;
@@ -383,33 +384,46 @@ void ora_keyswitch(const ora_ctx* c, int lvl, const u64* cx, const u64* key, int
             }
         }
     }
-    /* ModDown: out = (accQ - NTT(ModUpPtoQ_centered(INTT(accP)))) * P^-1 */
+    free(ext); free(cxi);
+}
+
+/* ModDown of ONE polynomial over Q_lvl u P (NTT domain, [L + np][n]; its P rows are left in the coefficient domain):
+ * out = (accQ - NTT(ModUpPtoQ_centered(INTT(accP)))) * P^-1   (Lattigo BasisExtender.ModDownQPtoQNTT) */
+void ora_moddown(const ora_ctx* c, int lvl, u64* acc, u64* out) {
+    int n = c->n, L = lvl + 1, np = c->np, nq = c->nq;
     int pidx[ORA_MAX_MOD], qidx[ORA_MAX_MOD];
     for (int i = 0; i < np; i++) pidx[i] = nq + i;
     for (int i = 0; i < L; i++) qidx[i] = i;
     u64* conv = (u64*)malloc(sizeof(u64) * L * n);
-    for (int h = 0; h < 2; h++) {
-        u64* acc = h ? acc1 : acc0;
-        u64* out = h ? out1 : out0;
-        const u64* srcp[ORA_MAX_MOD];
-        u64* dstp[ORA_MAX_MOD];
-        for (int i = 0; i < np; i++) {
-            ora_intt(c, nq + i, acc + (size_t)(L + i) * n);
-            srcp[i] = acc + (size_t)(L + i) * n;
-        }
-        for (int i = 0; i < L; i++) dstp[i] = conv + (size_t)i * n;
-        ora_baseconv(c, pidx, np, qidx, L, srcp, dstp, 1);
-        for (int i = 0; i < L; i++) {
-            u64 q = c->mod[i];
-            ora_ntt(c, i, conv + (size_t)i * n);
-            u64 pinv = 1;
-            for (int l = 0; l < np; l++) pinv = ora_mulmod(pinv, c->mod[nq + l] % q, q);
-            pinv = invmod(pinv, q);
-            for (int x = 0; x < n; x++)
-                out[(size_t)i * n + x] = ora_mulmod(submod(acc[(size_t)i * n + x], conv[(size_t)i * n + x], q), pinv, q);
-        }
+    const u64* srcp[ORA_MAX_MOD];
+    u64* dstp[ORA_MAX_MOD];
+    for (int i = 0; i < np; i++) {
+        ora_intt(c, nq + i, acc + (size_t)(L + i) * n);
+        srcp[i] = acc + (size_t)(L + i) * n;
     }
-    free(conv); free(ext); free(acc0); free(acc1); free(cxi);
+    for (int i = 0; i < L; i++) dstp[i] = conv + (size_t)i * n;
+    ora_baseconv(c, pidx, np, qidx, L, srcp, dstp, 1);
+    for (int i = 0; i < L; i++) {
+        u64 q = c->mod[i];
+        ora_ntt(c, i, conv + (size_t)i * n);
+        u64 pinv = 1;
+        for (int l = 0; l < np; l++) pinv = ora_mulmod(pinv, c->mod[nq + l] % q, q);
+        pinv = invmod(pinv, q);
+        for (int x = 0; x < n; x++)
+            out[(size_t)i * n + x] = ora_mulmod(submod(acc[(size_t)i * n + x], conv[(size_t)i * n + x], q), pinv, q);
+    }
+    free(conv);
+}
+
+void ora_keyswitch(const ora_ctx* c, int lvl, const u64* cx, const u64* key, int klvl,
+                   u64* out0, u64* out1) {
+    int T = lvl + 1 + c->np;
+    u64* acc0 = (u64*)malloc(sizeof(u64) * (size_t)T * c->n);
+    u64* acc1 = (u64*)malloc(sizeof(u64) * (size_t)T * c->n);
+    ora_gadget_product(c, lvl, cx, key, klvl, acc0, acc1);
+    ora_moddown(c, lvl, acc0, out0);
+    ora_moddown(c, lvl, acc1, out1);
+    free(acc0); free(acc1);
 }
 
 /* ------------------------------------------------------------------ CKKS */

@@ -83,6 +83,12 @@ void ora_automorph_coeff(const ora_ctx* c, int mi, uint64_t g, const uint64_t* a
  * out0,out1: [L][N] NTT domain. */
 void ora_keyswitch(const ora_ctx* c, int lvl, const uint64_t* cx, const uint64_t* key, int klvl,
                    uint64_t* out0, uint64_t* out1);
+/* its two halves (double-hoisted linear transforms keep sums over Q u P between them, Lattigo ckks/linear_transform.go
+ * MultiplyByDiagMatrixBSGS): the gadget product alone, acc0 / acc1 = [L+np][N] over Q_lvl u P, NTT domain, not divided by P;
+ * and the ModDown of one such polynomial (acc's P rows are left in the coefficient domain), out = [L][N]. */
+void ora_gadget_product(const ora_ctx* c, int lvl, const uint64_t* cx, const uint64_t* key, int klvl,
+                        uint64_t* acc0, uint64_t* acc1);
+void ora_moddown(const ora_ctx* c, int lvl, uint64_t* acc, uint64_t* out);
 
 /* CKKS (NTT domain ciphertexts, layout [poly][L][N]) */
 void ora_ckks_mult(const ora_ctx* c, int lvl, const uint64_t* a, const uint64_t* b, uint64_t* d3);

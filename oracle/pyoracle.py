@@ -65,6 +65,8 @@ def lib():
             "ora_automorph_ntt": [vp, u, u64p, u64p],
             "ora_automorph_coeff": [vp, i, u, u64p, u64p],
             "ora_keyswitch": [vp, i, u64p, u64p, i, u64p, u64p],
+            "ora_gadget_product": [vp, i, u64p, u64p, i, u64p, u64p],
+            "ora_moddown": [vp, i, u64p, u64p],
             "ora_ckks_mult": [vp, i, u64p, u64p, u64p],
             "ora_ckks_relin": [vp, i, u64p, u64p, i, u64p],
             "ora_ckks_rescale": [vp, i, u64p, i, u64p],
@@ -176,6 +178,21 @@ class Oracle:
         o1 = np.empty((L, self.n), dtype=np.uint64)
         lib().ora_keyswitch(self.h, lvl, _p(cx), _p(key), klvl, _p(o0), _p(o1))
         return o0, o1
+
+    def gadget_product(self, lvl, cx, key, klvl):
+        """the key switch without its division by P: [2][lvl+1+np][N] over Q_lvl u P, NTT domain"""
+        cx = np.ascontiguousarray(cx, dtype=np.uint64)
+        acc = np.empty((2, lvl + 1 + len(self.p), self.n), dtype=np.uint64)
+        lib().ora_gadget_product(self.h, lvl, _p(cx), _p(key), klvl, _p(acc[0]), _p(acc[1]))
+        return acc
+
+    def moddown(self, lvl, ext):
+        """[polys][lvl+1+np][N] over Q_lvl u P (NTT domain) -> [polys][lvl+1][N]: rounded division by P"""
+        ext = np.array(ext, dtype=np.uint64, order="C")   # a copy: the P rows are transformed in place
+        out = np.empty((ext.shape[0], lvl + 1, self.n), dtype=np.uint64)
+        for h in range(ext.shape[0]):
+            lib().ora_moddown(self.h, lvl, _p(ext[h]), _p(out[h]))
+        return out
 
     def ckks_mult(self, lvl, a, b):
         d = np.empty((3, lvl + 1, self.n), dtype=np.uint64)

@@ -28,9 +28,14 @@ def _oracle_plains(plan):
     return plan.oracle_plains()
 
 
-@pytest.mark.parametrize("log_n,encapsulate", [(10, False), (11, True)])
-def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate):
+@pytest.mark.parametrize("log_n,encapsulate,double_hoist", [(10, False, True), (11, True, True), (10, False, False)])
+def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate, double_hoist, monkeypatch):
+    """double_hoist (the default): the baby-step / giant-step matrices keep their sums over Q u P and divide by P once per giant
+    step and once at the end; False (LSA_BT_DOUBLE_HOIST=0 when the plan is made): one division per rotation.  The oracle
+    program follows the plan's choice; either way device == oracle bit for bit."""
     need_gpu()
+    if not double_hoist:
+        monkeypatch.setenv("LSA_BT_DOUBLE_HOIST", "0")
     from lattisense_amd.device import BootstrapPlan
     from oracle.ckks_bootstrap import Bootstrapper, Ct, Evaluator
     from oracle.client import Client, mean_precision_bits
@@ -39,6 +44,7 @@ def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate):
     D = float(2 ** 40)
     plan = BootstrapPlan(ctx, in_scale=D, out_scale=D)
     assert plan.out_level == 9 and plan.out_scale == D          # btp_output_level, parameter scale
+    assert plan.double_hoist == double_hoist
     ev = Evaluator(o, c, top)
     rlk = ctx.upload_key(ev.rlk, top)
     keys = {e: c.gen_galois_key(e, top) for e in plan.galois_elements}
@@ -57,7 +63,7 @@ def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate):
     out = plan.run(ctx.upload(cts), batch, rlk, glk, kd, ks)
     got = ctx.download(out, (batch, 2, plan.out_level + 1, N))
     # the oracle program with the device plan's constants
-    bt = Bootstrapper(ev, out_scale=D, plains=_oracle_plains(plan), coeffs=plan.chebyshev())
+    bt = Bootstrapper(ev, out_scale=D, plains=_oracle_plains(plan), coeffs=plan.chebyshev(), double_hoist=plan.double_hoist)
     for b in range(batch):
         want = bt.bootstrap(Ct(cts[b], 0, D), top, dts, std)
         assert want.level == plan.out_level and want.scale == D
@@ -115,9 +121,9 @@ def test_bootstrap_node_through_the_task_boundary(fixture):
     plains = plan.oracle_plains()
     cfg = (P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"], P["btp_eval_mod_message_ratio"])
     if sparse:
-        bt = SparseBootstrapper(ev, ns.bit_length() - 1, *cfg, out_scale=D, plains=plains, coeffs=plan.chebyshev())
+        bt = SparseBootstrapper(ev, ns.bit_length() - 1, *cfg, out_scale=D, plains=plains, coeffs=plan.chebyshev(), double_hoist=plan.double_hoist)
     else:
-        bt = Bootstrapper(ev, *cfg, out_scale=D, plains=plains, coeffs=plan.chebyshev())
+        bt = Bootstrapper(ev, *cfg, out_scale=D, plains=plains, coeffs=plan.chebyshev(), double_hoist=plan.double_hoist)
     for i in range(2):
         re, im = mean_precision_bits(zs[i], c.ckks_decrypt(ys[i].data, D)[:ns])
         assert re >= 10 and im >= 10
@@ -150,7 +156,7 @@ def test_sparse_slot_bootstrap_bit_exact_against_the_oracle_program():
     ct = c.ckks_encrypt(np.tile(z, (N // 2) // ns), 0, D)
     out = plan.run(ctx.upload(ct[None]), 1, rlk, glk)
     got = ctx.download(out, (1, 2, plan.out_level + 1, N))[0]
-    want = SparseBootstrapper(ev, log_slots, out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev()).bootstrap(
+    want = SparseBootstrapper(ev, log_slots, out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev(), double_hoist=plan.double_hoist).bootstrap(
         Ct(ct, 0, D), top)
     assert np.array_equal(got, want.data)
     re, im = mean_precision_bits(z, c.ckks_decrypt(got, D)[:ns])
@@ -200,7 +206,7 @@ def test_multiply_then_bootstrap_task():
     plan = BootstrapPlan(ctx, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
                          P["btp_eval_mod_message_ratio"], D, D)
     bt = Bootstrapper(ev, P["btp_cts_depth"], P["btp_stc_depth"], P["btp_eval_mod_k"], P["btp_eval_mod_double_angle"],
-                      P["btp_eval_mod_message_ratio"], out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev())
+                      P["btp_eval_mod_message_ratio"], out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev(), double_hoist=plan.double_hoist)
     prod_scale = D * D / q[lvl]
     for i in range(2):
         z = o.ckks_mult_relin_rescale(lvl, xs[i], ys[i], ev.rlk, top)[:, :1]          # level 2, dropped to level 0
@@ -232,24 +238,28 @@ def test_device_constants_against_independently_computed_ones(log_n):
     plan = BootstrapPlan(ctx, in_scale=D, out_scale=D)
     ev = Evaluator.__new__(Evaluator)          # no keys needed: only q() and encode() are used
     ev.o, ev.c, ev.n = o, c, N
-    want, coeffs, out_level = Bootstrapper(ev, out_scale=D).expected_constants(D, top)
+    want, coeffs, out_level = Bootstrapper(ev, out_scale=D, double_hoist=plan.double_hoist).expected_constants(D, top)
     assert out_level == plan.out_level
     dev = plan.oracle_plains()
+    levels = plan.oracle_levels()
     assert sorted(dev) == sorted(want)
+    assert plan.double_hoist                                        # the default: special-prime rows on the BSGS matrices
     worst = 0.0
     for key in sorted(want):
         assert sorted(dev[key]) == sorted(want[key]), key          # the same diagonal index set
         for k in want[key]:
             a, b = dev[key][k], want[key][k]
             assert a.shape == b.shape, (key, k)
-            lvl = a.shape[0] - 1
+            lvl = levels[key]
+            assert a.shape[0] in (lvl + 1, lvl + 1 + len(o.p))
             deltas = []
-            for j in (0, lvl):
+            for row in (0, lvl, a.shape[0] - 1):                    # first and last prime of the level, last row (a special prime
+                j = ev._mi(lvl, row)                                # when the matrix is double-hoisted)
                 q = o.mod[j]
-                d = (o.intt(j, a[j]).astype(object) - o.intt(j, b[j]).astype(object)) % q
+                d = (o.intt(j, a[row]).astype(object) - o.intt(j, b[row]).astype(object)) % q
                 d = np.array([int(x) - q if int(x) > q // 2 else int(x) for x in d], dtype=np.float64)
                 deltas.append(d)
-            assert np.array_equal(deltas[0], deltas[1]), (key, k)   # one integer polynomial, not per-limb noise
+            assert np.array_equal(deltas[0], deltas[1]) and np.array_equal(deltas[0], deltas[2]), (key, k)   # one integer polynomial, not per-limb noise
             rel = np.max(np.abs(deltas[0])) / float(o.mod[lvl])
             worst = max(worst, rel)
             assert rel < 2.0 ** -30, (key, k, rel)
@@ -334,7 +344,7 @@ def test_wider_evalmod_configurations(sine_deg, arcsine_deg):
     cts = np.stack([c.ckks_encrypt(z, 0, D)])
     out = plan.run(ctx.upload(cts), 1, rlk, glk)
     got = ctx.download(out, (1, 2, plan.out_level + 1, N))
-    bt = Bootstrapper(ev, out_scale=D, plains=plan.oracle_plains(), coeffs=cheb, sine_deg=sine_deg, arcsine_deg=arcsine_deg, asin=asin)
+    bt = Bootstrapper(ev, out_scale=D, plains=plan.oracle_plains(), coeffs=cheb, sine_deg=sine_deg, arcsine_deg=arcsine_deg, asin=asin, double_hoist=plan.double_hoist)
     want = bt.bootstrap(Ct(cts[0], 0, D), top)
     assert want.level == plan.out_level and want.scale == D
     assert np.array_equal(got[0], want.data)

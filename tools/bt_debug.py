@@ -28,7 +28,7 @@ plains = {}
 for i in range(plan.n_matrices):
     _, _, _, pts = plan.matrix(i)
     plains[("cts", i) if i < plan.n_cts else ("stc", i - plan.n_cts)] = pts
-bt = Bootstrapper(ev, out_scale=D, plains=plains, coeffs=plan.chebyshev())
+bt = Bootstrapper(ev, out_scale=D, plains=plains, coeffs=plan.chebyshev(), double_hoist=plan.double_hoist)
 # oracle intermediates
 inter = []
 x = Ct(ct0, 0, D)
@@ -36,7 +36,7 @@ cc = max(1, int(round(ev.q(0) / (bt.mr * x.scale))))
 x = ev.mul_int(x, cc); inter.append(("mul_int", x))
 x = Ct(bt.mod_raise(x, top), top, float(ev.q(0))); inter.append(("mod_raise", x))
 for i, m in enumerate(bt.cts):
-    x = linear_transform(ev, x, m, plains=plains[("cts", i)]); inter.append(("cts%d" % i, x))
+    x = linear_transform(ev, x, m, plains=plains[("cts", i)], double_hoist=plan.double_hoist); inter.append(("cts%d" % i, x))
 xc = ev.conj(x)
 u_re = ev.add(x, xc); inter.append(("u_re", u_re))
 u_im = ev.mul_by_i(ev.sub(x, xc), -1); inter.append(("u_im", u_im))

@@ -30,9 +30,9 @@ for logn, cd, sd, K, r, ls in [(10, 3, 3, 16, 3, 0), (10, 2, 2, 16, 3, 0), (11, 
     ct = c.ckks_encrypt(np.tile(z, (N // 2) // ns), 0, D)
     got = ctx.download(plan.run(ctx.upload(ct[None]), 1, rlk, glk), (1, 2, plan.out_level + 1, N))[0]
     if plan.sparse:
-        bt = SparseBootstrapper(ev, ls, cd, sd, K, r, 256.0, out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev())
+        bt = SparseBootstrapper(ev, ls, cd, sd, K, r, 256.0, out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev(), double_hoist=plan.double_hoist)
     else:
-        bt = Bootstrapper(ev, cd, sd, K, r, 256.0, out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev())
+        bt = Bootstrapper(ev, cd, sd, K, r, 256.0, out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev(), double_hoist=plan.double_hoist)
     want = bt.bootstrap(Ct(ct, 0, D), top)
     prec = mean_precision_bits(z, c.ckks_decrypt(got, D)[:ns])
     print((logn, cd, sd, K, r, ls), "out level", plan.out_level, "bit-exact", bool(np.array_equal(got, want.data)), "prec %.1f/%.1f" % prec, "keys", len(keys))

@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/be
 cd $REPO && python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 f = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_stats.csv"), recursive=True))[-1]
-for r in list(csv.DictReader(open(f)))[:16]:
+for r in list(csv.DictReader(open(f)))[:26]:
     n = r["Name"].replace("lsa::", "").replace("void ", "")
     print("%-64s calls=%-5s avg_us=%-9.1f total_ms=%-9.2f pct=%s" % (n[:64], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 PY
