@@ -204,8 +204,15 @@ __global__ __launch_bounds__(LSA_R16_THREADS, FP ? LSA_KSMAC_WAVES_FP : LSA_KSMA
     const int tid = threadIdx.x;
     const int T = g.L + g.np;
     long long bid = blockIdx.x;
-    const long long b = bid % g.batch;
-    bid /= g.batch;
+    long long b;
+    if (g.xcd_deal) {   // consecutive workgroup ids go round-robin over the 8 XCDs: the batch of one key tile stays on one
+        const long long slot = bid >> 3;
+        b = slot % g.batch;
+        bid = (slot / g.batch) * 8 + (bid & 7);
+    } else {
+        b = bid % g.batch;
+        bid /= g.batch;
+    }
     const int tl = g.tl_list[bid % g.n_tl], tile = (int)(bid / g.n_tl);
     NttPassArgs a;   // only the scalar fields the pass functions read are set (the row tables are never indexed here)
     a.logn = g.logn;
@@ -329,6 +336,11 @@ bool launch_ntt_ksmac(Context& c, int level, const u64* cx, long long scx, u64* 
         if (!g.n_tl) continue;
         const long long nblocks = (long long)batch * g.n_tl * (1 << (c.logn - 12));
         LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
+        static const bool xcd = [] {
+            const char* e = getenv("LSA_KSMAC_XCD");   // =0: plain batch-fastest order (A/B: +0.45 % headline with the deal, ab_ksmac_xcd_deal.log)
+            return !(e && e[0] == '0');
+        }();
+        g.xcd_deal = xcd && ((g.n_tl << (c.logn - 12)) % 8 == 0) ? 1 : 0;
         const double ntt_bytes = 16.0 * c.n * transforms * batch / 2;
         ProfScope ps(c, PROF_NTT, ntt_bytes + 8.0 * c.n * g.n_tl * (batch * ((double)g.beta + 2.0) + 2.0 * g.beta), s, ntt_bytes);
         const dim3 grid((unsigned)nblocks), block(LSA_R16_THREADS);

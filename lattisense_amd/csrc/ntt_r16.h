@@ -452,6 +452,7 @@ struct KsFusedArgs {
     const u64* tw;
     const double* twd;
     int logn, L, np, nq, beta, kcomp, klvl, batch, allow_fp64, fp_raw_in;
+    int xcd_deal;                  // 1: the workgroups of one (tile, limb) -- one key tile -- are dealt to one XCD: one key fetch instead of eight (LSA_KSMAC_XCD=0 off)
     int n_tl;                      // target limbs of this launch (one launch per butterfly engine: each has its own register budget)
     unsigned char tl_list[64];
 };
