@@ -7,13 +7,19 @@ Default workload (the configuration the metric is quoted on, BASELINE.json confi
 A "step" = one pass of the operator over the whole batch.  value = ciphertexts/s over all ranks.
 
 Other workloads (--workload): ntt (configs[1]: BFV N=2^14, 4 primes, batch 1024 cts fwd+inv NTT; value = GB/s),
-rotate (configs[3] shape per GPU), bfv_hmult (examples/benchmark_gpu shape), deep (configs[4] deep-chain key switch).
+rotate (configs[3] shape per GPU), bfv_hmult (examples/benchmark_gpu shape), deep / deep17 (configs[4] deep-chain key switch at
+N=2^16 / 2^17), bootstrap (the reference's bootstrap parameter set), task_ckks / task_bfv / task_conv (T2: the same
+operators through run_fhe_gpu_task from host C structs, PCIe inclusive -- reported, never `value` of the default run).
+
+Operator workloads time TWO regions in one run: the two-stream tile runner (alternate tiles of the batch on an auxiliary
+stream; this is `value`) and a single-stream region (`single_stream`), on whose launch stream the `roofline` sample is taken.
 
 Multi-GPU (torchrun, one rank per GPU): the ciphertext batch is sharded by index (weak scaling: `batch` per rank),
 no steady-state collective; rank 0 "ingests" the evaluation key and broadcasts it once over RCCL/xGMI.
 
 The JSON line also carries
-  roofline     — k_ntt_pass (dominant kernel): algorithmic bytes / HIP-event duration, sampled live in the timed region
+  roofline     — the limb-transform passes (k_ntt_r16 / k_ntt_pass, the dominant kernel family): algorithmic bytes / HIP-event
+                 duration, sampled live on the launch stream; `traffic` from the committed PMC passes of the same command
   cpu_baseline — the CPU oracle ("port") timed on rank 0's host cores on a bounded sample of the same workload.
 """
 import argparse
