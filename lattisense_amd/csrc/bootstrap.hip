@@ -30,6 +30,8 @@ void ckks_rotate_many(Context&, int, const u64*, int, const u64*, const Key* con
                       hipStream_t);
 void ckks_mult_relin_rescale(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long, long long,
                              hipStream_t);
+void ckks_mult_relin_rescale_rpp(Context&, int, const u64*, const u64*, const Key&, u64*, int, long long, long long, long long,
+                                 hipStream_t, int, int);
 void ckks_lift_ext(Context&, int, const u64*, u64*, int, long long, long long, hipStream_t);
 void ckks_rotate_many_ext(Context&, int, const u64*, int, const u64*, const Key* const*, u64* const*, int, long long, long long,
                           hipStream_t);
@@ -568,25 +570,18 @@ struct Eval {
     }
     DCt add(const DCt& a, const DCt& b) { return addsub(a, b, EW_ADD); }
     DCt sub(const DCt& a, const DCt& b) { return addsub(a, b, EW_SUB); }
-    DCt drop(const DCt& a, int level) {
-        if (level == a.level) return a;
-        DCt o = alloc(level, a.scale);
-        std::vector<int> rows;
-        for (int p = 0; p < 2; p++)
-            for (int j = 0; j <= level; j++) rows.push_back(p * (a.level + 1) + j);
-        launch_copy_rows(c, a.data(), stride(a.level), o.data(), stride(level), (int)rows.size(), rows.data(), m, s);
-        return o;
-    }
     DCt rescale(const DCt& a) {
         DCt o = alloc(a.level - 1, a.scale / q(a.level));
         ckks_rescale(c, a.level, 2, a.data(), o.data(), m, stride(a.level), stride(a.level - 1), s);
         return o;
     }
     DCt mul(const DCt& a0, const DCt& b0) {
+        // operands at different levels: the leading rows of each polynomial of the higher one ARE it at the lower level, the
+        // tensor kernel takes the rows per polynomial -- no copy (k_copy_rows was 2 % of a bootstrap)
         const int lvl = std::min(a0.level, b0.level);
-        DCt a = drop(a0, lvl), b = drop(b0, lvl);
-        DCt o = alloc(lvl - 1, a.scale * b.scale / q(lvl));
-        ckks_mult_relin_rescale(c, lvl, a.data(), b.data(), rlk, o.data(), m, stride(lvl), stride(lvl), stride(lvl - 1), s);
+        DCt o = alloc(lvl - 1, a0.scale * b0.scale / q(lvl));
+        ckks_mult_relin_rescale_rpp(c, lvl, a0.data(), b0.data(), rlk, o.data(), m, stride(a0.level), stride(b0.level), stride(lvl - 1), s,
+                                    a0.level + 1, b0.level + 1);
         return o;
     }
     const Key& gkey(u64 e) const {
@@ -685,16 +680,20 @@ struct Eval {
         const std::string name = std::string(montgomery ? "btm" : "btr") + std::to_string(level) + "_" + std::to_string(k);
         return montgomery ? c.const_vec(name, mods, vals) : c.raw_vec(name, vals);
     }
-    DCt mul_int_raw(const DCt& a, long long k, double new_scale) {
-        DCt o = alloc(a.level, new_scale);
+    // level < a.level: the product at that lower level, read from a's leading rows (no copy to drop it first)
+    DCt mul_int_raw(const DCt& a, long long k, double new_scale, int level = -1) {
+        if (level < 0) level = a.level;
+        DCt o = alloc(level, new_scale);
         unsigned char lm[LSA_MAX_PERIOD];
-        for (int j = 0; j <= a.level; j++) lm[j] = (unsigned char)j;
-        launch_sub_mul_general(c, 2, a.level + 1, lm, kvec(k, a.level, true), a.data(), stride(a.level), a.level + 1, nullptr, 0,
-                               0, nullptr, 0, 0, 0, o.data(), stride(a.level), a.level + 1, m, s);
+        for (int j = 0; j <= level; j++) lm[j] = (unsigned char)j;
+        launch_sub_mul_general(c, 2, level + 1, lm, kvec(k, level, true), a.data(), stride(a.level), a.level + 1, nullptr, 0,
+                               0, nullptr, 0, 0, 0, o.data(), stride(level), level + 1, m, s);
         return o;
     }
     DCt mul_int(const DCt& a, long long k) { return mul_int_raw(a, k, a.scale); }
-    DCt mul_const(const DCt& a, double cst, double const_scale) { return mul_int_raw(a, round_even(cst * const_scale), a.scale * const_scale); }
+    DCt mul_const(const DCt& a, double cst, double const_scale, int level = -1) {
+        return mul_int_raw(a, round_even(cst * const_scale), a.scale * const_scale, level);
+    }
     // per-row vectors over BOTH polynomials: [value for the L limbs of c0 | `second` for the L limbs of c1]
     const u64* kvec2(long long k0, long long k1, int level, bool montgomery) {
         const int L = level + 1;
@@ -922,9 +921,8 @@ struct Eval {
         std::function<DCt(const std::vector<double>&, int, double)> rec = [&](const std::vector<double>& cf, int level_out,
                                                                               double scale_out) -> DCt {
             if (cf.size() == 2) {
-                DCt t1 = drop(u, level_out + 1);
-                const double cs = scale_out * q(level_out + 1) / t1.scale;
-                DCt rr = rescale(mul_const(t1, cf[1], cs));
+                const double cs = scale_out * q(level_out + 1) / u.scale;
+                DCt rr = rescale(mul_const(u, cf[1], cs, level_out + 1));
                 rr.scale = scale_out;
                 return add_const(rr, cf[0]);
             }
@@ -935,7 +933,7 @@ struct Eval {
                 hi[j] = 2 * cf[half + j];
                 lo[half - j] -= cf[half + j];
             }
-            DCt th = drop(powers[(int)half], level_out + 1);
+            const DCt& th = powers[(int)half];   // at or above level_out + 1: mul() reads its leading rows
             DCt h = rec(hi, level_out + 1, scale_out * q(level_out + 1) / th.scale);
             DCt prod = mul(h, th);
             prod.scale = scale_out;
@@ -958,15 +956,14 @@ struct Eval {
         std::function<DCt(const std::vector<double>&, int, double)> rec = [&](const std::vector<double>& cf, int level_out,
                                                                               double scale_out) -> DCt {
             if (cf.size() == 2) {
-                DCt t1 = drop(u, level_out + 1);
-                const double cs = scale_out * q(level_out + 1) / t1.scale;
-                DCt rr = rescale(mul_const(t1, cf[1], cs));
+                const double cs = scale_out * q(level_out + 1) / u.scale;
+                DCt rr = rescale(mul_const(u, cf[1], cs, level_out + 1));
                 rr.scale = scale_out;
                 return add_const(rr, cf[0]);
             }
             const size_t half = cf.size() / 2;
             std::vector<double> hi(cf.begin() + half, cf.end()), lo(cf.begin(), cf.begin() + half);
-            DCt th = drop(powers[(int)half], level_out + 1);
+            const DCt& th = powers[(int)half];   // at or above level_out + 1: mul() reads its leading rows
             DCt h = rec(hi, level_out + 1, scale_out * q(level_out + 1) / th.scale);
             DCt prod = mul(h, th);
             prod.scale = scale_out;

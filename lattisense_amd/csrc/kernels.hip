@@ -844,6 +844,7 @@ struct TensorArgs {
     const u64* b;
     u64* d;
     long long sa, sb, sd;
+    long long pa, pb;   // elements between the two polynomials of a / b (operands kept at a higher level: more rows per polynomial)
     const ModDev* mods;
     int limbs, logn;
     unsigned char mod_of[LSA_MAX_PERIOD];
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(TPB) void k_tensor(TensorArgs g) {
     const u64* pa = g.a + b * g.sa + off;
     const u64* pb = g.b + b * g.sb + off;
     u64* pd = g.d + b * g.sd + off;
-    const ulonglong2 a0 = ld2(pa), a1 = ld2(pa + poly), b0 = ld2(pb), b1 = ld2(pb + poly);
+    const ulonglong2 a0 = ld2(pa), a1 = ld2(pa + g.pa), b0 = ld2(pb), b1 = ld2(pb + g.pb);
     u64 r[3][2];
     const u64 a0v[2] = {a0.x, a0.y}, a1v[2] = {a1.x, a1.y}, b0v[2] = {b0.x, b0.y}, b1v[2] = {b1.x, b1.y};
 #pragma unroll
@@ -877,9 +878,12 @@ __global__ __launch_bounds__(TPB) void k_tensor(TensorArgs g) {
 }
 
 void launch_tensor(Context& c, const u64* a, const u64* b, u64* d, int batch, long long sa, long long sb, long long sd,
-                   int limbs, const RowMap& rm, hipStream_t s) {
+                   int limbs, const RowMap& rm, hipStream_t s, int a_rpp, int b_rpp) {
     if (batch <= 0) return;
     TensorArgs g{};
+    LSA_REQUIRE((a_rpp == 0 || a_rpp >= limbs) && (b_rpp == 0 || b_rpp >= limbs), "tensor: rows per polynomial below the limb count");
+    g.pa = (long long)(a_rpp ? a_rpp : limbs) << c.logn;
+    g.pb = (long long)(b_rpp ? b_rpp : limbs) << c.logn;
     g.a = a;
     g.b = b;
     g.d = d;

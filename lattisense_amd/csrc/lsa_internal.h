@@ -243,8 +243,10 @@ void launch_mac_plain_multi(Context& c, int nb, const u64* const* ct, const long
 void launch_lift_ringt(Context& c, int mode, int level, const u64* pt, long long spt, u64* out, long long sout, int batch,
                        hipStream_t s);
 // CKKS/BFV tensor: a,b [2][T][N] -> d [3][T][N]; limb i uses modulus rm.mod_of[i]
+// a_rpp / b_rpp: rows per polynomial of the operands (0 = limbs; more when an operand is kept at a higher level: its first
+// `limbs` rows of each polynomial are the operand at this level -- no copy needed to "drop" it)
 void launch_tensor(Context& c, const u64* a, const u64* b, u64* d, int batch, long long sa, long long sb, long long sd,
-                   int limbs, const RowMap& rm, hipStream_t s);
+                   int limbs, const RowMap& rm, hipStream_t s, int a_rpp = 0, int b_rpp = 0);
 // exact base conversion: src limbs at rows src_row[i] of the source item, dst limbs at rows dst_row[j] of the dest item
 struct BaseConvRows {
     int src_row[LSA_BC_MAX_SRC];

@@ -497,8 +497,16 @@ void ckks_switch_key(Context& c, int level, const u64* in, const Key& swk, u64* 
     });
 }
 
+void ckks_mult_relin_rescale_rpp(Context& c, int level, const u64* a, const u64* b, const Key& rlk, u64* out, int batch,
+                                 long long sa, long long sb, long long so, hipStream_t s, int a_rpp, int b_rpp);
 void ckks_mult_relin_rescale(Context& c, int level, const u64* a, const u64* b, const Key& rlk, u64* out, int batch,
                              long long sa, long long sb, long long so, hipStream_t s) {
+    ckks_mult_relin_rescale_rpp(c, level, a, b, rlk, out, batch, sa, sb, so, s, 0, 0);
+}
+// a_rpp / b_rpp: rows per polynomial of a / b when an operand sits at a higher level than `level` (0: level + 1) -- its leading
+// rows ARE the operand at this level, so callers with operands at mixed levels (polynomial evaluation) need no copies
+void ckks_mult_relin_rescale_rpp(Context& c, int level, const u64* a, const u64* b, const Key& rlk, u64* out, int batch,
+                                 long long sa, long long sb, long long so, hipStream_t s, int a_rpp, int b_rpp) {
     LSA_REQUIRE(level >= 1, "mult+relin+rescale needs level >= 1");
     const long long N = c.n;
     const int L = level + 1;
@@ -509,7 +517,7 @@ void ckks_mult_relin_rescale(Context& c, int level, const u64* a, const u64* b, 
         u64* d3 = ws;
         u64* r2 = d3 + r_d3 * N * tb;
         u64* sub = r2 + r_r2 * N * tb;
-        launch_tensor(c, a + (size_t)b0 * sa, b + (size_t)b0 * sb, d3, nb, sa, sb, sd, L, rm_seq(L), st);
+        launch_tensor(c, a + (size_t)b0 * sa, b + (size_t)b0 * sb, d3, nb, sa, sb, sd, L, rm_seq(L), st, a_rpp, b_rpp);
         if (c.fuse_tails) {
             const KsRescale rs{out + (size_t)b0 * so, so};
             key_switch(c, level, d3 + 2LL * L * N, sd, rlk, r2, sr, d3, sd, L, 2, nb, sub, st, &rs);

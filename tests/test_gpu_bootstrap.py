@@ -351,3 +351,52 @@ def test_wider_evalmod_configurations(sine_deg, arcsine_deg):
     re, im = mean_precision_bits(z, c.ckks_decrypt(got[0], D))
     assert re >= 10 and im >= 10, (re, im)
     plan.close()
+
+
+@pytest.mark.parametrize("log_n,cts_depth,stc_depth,log_slots", [(10, 2, 2, 0), (10, 3, 3, 0), (11, 2, 3, 7)])
+def test_other_matrix_depths_bit_exact(log_n, cts_depth, stc_depth, log_slots):
+    """CoeffsToSlots / SlotsToCoeffs depths other than the reference default (btp_cts_depth / btp_stc_depth are plain parameters,
+    gpu_wrapper.cu:94-99): depth 2 gives 32- and 63-diagonal matrices -- more than 8 baby steps, so the inner sums take the
+    one-launch-per-giant-step path of the double-hoisted transform instead of the single multi-MAC launch -- also with sparse
+    packing.  Device == oracle program bit for bit, precision above the reference's bar."""
+    need_gpu()
+    from lattisense_amd import params
+    from lattisense_amd.device import ALGO_CKKS, BootstrapPlan, DeviceContext
+    from oracle.ckks_bootstrap import Bootstrapper, Ct, Evaluator, SparseBootstrapper
+    from oracle.client import Client, mean_precision_bits
+    from oracle.pyoracle import Oracle
+    B = params.CKKS_BOOTSTRAP_65536
+    N = 1 << log_n
+    # the reference chain's shape (custom_task.py:387-420: q0, 9 output levels, StC primes, 8 EvalMod primes, CtS primes) with as
+    # many StC / CtS primes as the depths ask for
+    q = B["q"][:10] + B["q"][10:10 + stc_depth] + B["q"][13:21] + B["q"][21:21 + cts_depth]
+    o = Oracle(N, q, B["p"], 0)
+    c = Client(o, seed=log_n + cts_depth, hamming=32)
+    ctx = DeviceContext(ALGO_CKKS, N, q, B["p"])
+    top = len(q) - 1
+    D = float(2 ** 40)
+    plan = BootstrapPlan(ctx, cts_depth, stc_depth, 16, 3, 256.0, D, D, log_slots=log_slots)
+    assert plan.double_hoist
+    ev = Evaluator(o, c, top)
+    keys = {e: c.gen_galois_key(e, top) for e in plan.galois_elements}
+    ev.glk = dict(keys)
+    rlk = ctx.upload_key(ev.rlk, top)
+    glk = {e: ctx.upload_key(k, top) for e, k in keys.items()}
+    ns = (1 << log_slots) if log_slots else N // 2
+    rng = np.random.default_rng(log_n)
+    z = rng.uniform(-1, 1, ns) + 1j * rng.uniform(-1, 1, ns)
+    ct = c.ckks_encrypt(np.tile(z, (N // 2) // ns), 0, D)
+    got = ctx.download(plan.run(ctx.upload(ct[None]), 1, rlk, glk), (1, 2, plan.out_level + 1, N))[0]
+    cfg = dict(out_scale=D, plains=plan.oracle_plains(), coeffs=plan.chebyshev(), double_hoist=True)
+    if plan.sparse:
+        bt = SparseBootstrapper(ev, log_slots, cts_depth, stc_depth, 16, 3, 256.0, **cfg)
+    else:
+        bt = Bootstrapper(ev, cts_depth, stc_depth, 16, 3, 256.0, **cfg)
+    want = bt.bootstrap(Ct(ct, 0, D), top)
+    assert want.level == plan.out_level
+    assert np.array_equal(got, want.data)
+    re, im = mean_precision_bits(z, c.ckks_decrypt(got, D)[:ns])
+    assert re >= 10 and im >= 10
+    assert sorted(ev.glk) == sorted(plan.galois_elements)
+    plan.close()
+    ctx.close()
