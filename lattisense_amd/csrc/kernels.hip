@@ -421,7 +421,9 @@ void launch_ntt(Context& c, const u64* src, u64* dst, int batch, long long src_s
         a.fz_last_stride = fz->last_stride;
         a.fz_last_rpp = fz->last_rpp;
         a.fz_k2 = fz->k2;
+        a.fz_scatter = fz->scatter;
         LSA_REQUIRE(fz->epi != 2 || fz->k2, "merged tail needs its second factor");
+        LSA_REQUIRE(!fz->scatter || fz->epi, "a scattered store needs an epilogue");
     }
     a.period = rm.period;
     a.row0 = rm.row0;

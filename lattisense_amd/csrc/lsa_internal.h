@@ -218,6 +218,7 @@ struct NttFusion {
     long long last_stride = 0;
     int last_rpp = 1;            // rows between the polynomials' last limbs in `last`
     const u64* k2 = nullptr;     // epi == 2: out = (a*k - v + base) * k2
+    const u32* scatter = nullptr;   // epilogue only: out[scatter[x]] = value(x) within each row (the automorphism of a rotation)
 };
 // passes: bit 0 = the first executed pass, bit 1 = the second (two-pass plans; a caller that fuses the second pass into
 // another kernel asks for 1 only)

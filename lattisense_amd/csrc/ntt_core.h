@@ -100,6 +100,9 @@ struct NttPassArgs {
     const u64* fz_k;
     const u64* fz_k2;
     u64* fz_out;
+    // with an epilogue: out[perm^-1 ...] -- the result row is written through this index map, out[fz_scatter[x]] = value(x): the
+    // NTT-domain automorphism of a rotation applied by the store of the key switch's last pass (null: plain store)
+    const unsigned* fz_scatter;
     const u64* fz_last;
     long long fz_a_stride, fz_base_stride, fz_out_stride, fz_last_stride;
     unsigned long long* diag;   // diagnostic builds (LSA_NTT_DIAG_STAMPS): per-workgroup phase time stamps, else unused
@@ -574,6 +577,14 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
                     ntt_load_data_pair(pb + x, vb[2 * p], vb[2 * p + 1]);
                 }
             }
+            if (FZ && f.tail && a.fz_scatter) {   // block-uniform: a branch around the stores
+#pragma unroll
+                for (int p = 0; p < LSA_NTT_STORE_CHUNK; p++) {
+                    g[a.fz_scatter[xs[p]]] = ntt_store_fix(f, v[2 * p], va[2 * p], vb[2 * p]);
+                    g[a.fz_scatter[xs[p] + 1]] = ntt_store_fix(f, v[2 * p + 1], va[2 * p + 1], vb[2 * p + 1]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int p = 0; p < LSA_NTT_STORE_CHUNK; p++)
                 ntt_store_pair(g + xs[p], ntt_store_fix(f, v[2 * p], va[2 * p], vb[2 * p]),
@@ -585,7 +596,13 @@ LSA_HD void ntt_phase_store(const NttPassArgs& a, const NttBlockCtx& bc, int tid
         const int x = ntt_tile_index(tm, 2 * i);
         const u64 a0 = f.tail ? pa[x] : 0, a1 = f.tail ? pa[x + 1] : 0;
         const u64 b0 = f.with_base ? pb[x] : 0, b1 = f.with_base ? pb[x + 1] : 0;
-        ntt_store_pair(g + x, ntt_store_fix(f, lds[lds_addr(2 * i)], a0, b0), ntt_store_fix(f, lds[lds_addr(2 * i + 1)], a1, b1));
+        const u64 w0 = ntt_store_fix(f, lds[lds_addr(2 * i)], a0, b0), w1 = ntt_store_fix(f, lds[lds_addr(2 * i + 1)], a1, b1);
+        if (FZ && f.tail && a.fz_scatter) {
+            g[a.fz_scatter[x]] = w0;
+            g[a.fz_scatter[x + 1]] = w1;
+        } else {
+            ntt_store_pair(g + x, w0, w1);
+        }
     }
 }
 

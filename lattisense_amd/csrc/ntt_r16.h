@@ -214,7 +214,7 @@ LSA_HD void r16_store_direct(const NttPassArgs& a, const NttBlockCtx& bc, int ti
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const long long x = r16_x<PASS, MU>(a, bc.tile, k, r16_pt<MU, IMAGE>(i, 8 * h + e));
-                r16_store1(g + x, ntt_store_fix(f, v[8 * h + e], va[e], vb[e]));
+                r16_store1(g + (a.fz_scatter ? (long long)a.fz_scatter[x] : x), ntt_store_fix(f, v[8 * h + e], va[e], vb[e]));
             }
         }
         return;
@@ -325,6 +325,14 @@ LSA_HD void r16_store_coalesced(const NttPassArgs& a, const NttBlockCtx& bc, int
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * LSA_NTT_STORE_CHUNK; j++) w[j] = ntt_store_fix(f, v[j], va[j], vb[j]);
+        }
+        if (FZ && f.tail && a.fz_scatter) {   // the rotation's index map applied by the store (block-uniform branch)
+#pragma unroll
+            for (int m = 0; m < LSA_NTT_STORE_CHUNK; m++) {
+                g[a.fz_scatter[xs[m]]] = w[2 * m];
+                g[a.fz_scatter[xs[m] + 1]] = w[2 * m + 1];
+            }
+            continue;
         }
 #pragma unroll
         for (int m = 0; m < LSA_NTT_STORE_CHUNK; m++) ntt_store_pair(g + xs[m], w[2 * m], w[2 * m + 1]);

@@ -42,7 +42,7 @@ struct KsRescale {
 // With `rs` (needs fused tails): p is scratch of the same shape and rs->out receives rescale(p).
 static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
-                      const KsRescale* rs, bool coeff_out = false, bool ext_first_pass_only = false);
+                      const KsRescale* rs, bool coeff_out = false, bool ext_first_pass_only = false, const u32* scatter = nullptr);
 
 // steps 1-3: cx out of the NTT domain, every digit converted to the other limbs of Q u P, extended limbs back into the
 // NTT domain (workspace layout: cxi | ext | acc | conv).  cx_coef: the same polynomial in the coefficient domain if the
@@ -154,23 +154,28 @@ static void ks_mac(Context& c, int level, const u64* cx, long long scx, const Ke
 }
 
 static void ks_moddown(Context& c, int level, u64* acc, long long s_acc, u64* conv, u64* p, long long sp, const u64* base,
-                       long long sbase, int base_rpp, int base_polys, int nb, hipStream_t s, const KsRescale* rs, bool coeff_out);
+                       long long sbase, int base_rpp, int base_polys, int nb, hipStream_t s, const KsRescale* rs, bool coeff_out,
+                       const u32* scatter = nullptr);
 
 // steps 4-5 of a key switch on the digits that ks_decompose left in the workspace: they depend on the key, the decomposition
 // does not -- rotations of ONE ciphertext by several Galois elements share it ("hoisting"; with the automorphism applied
 // after the switch, as here, every rotation's residues are the same as if it had been computed on its own)
 static void ks_finish(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                       const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
-                      const KsRescale* rs, bool coeff_out, bool ext_first_pass_only) {
+                      const KsRescale* rs, bool coeff_out, bool ext_first_pass_only, const u32* scatter) {
     const KsWorkspace w = ks_layout(c, level, nb, ws);
     ks_mac(c, level, cx, scx, key, nb, ws, s, ext_first_pass_only);
-    ks_moddown(c, level, w.acc, w.s_acc, w.conv, p, sp, base, sbase, base_rpp, base_polys, nb, s, rs, coeff_out);
+    ks_moddown(c, level, w.acc, w.s_acc, w.conv, p, sp, base, sbase, base_rpp, base_polys, nb, s, rs, coeff_out, scatter);
 }
 
 // step 5, the division by P of a polynomial pair over Q_level u P (acc: [2][L+k][N] per batch item, NTT domain; its P rows --
-// and, for the merged rescale, its last Q row -- are transformed in place), conv: 2L rows of scratch per batch item
+// and, for the merged rescale, its last Q row -- are transformed in place), conv: 2L rows of scratch per batch item.
+// scatter (fused tails only): every result row is written through the index map, p[row][scatter[x]] = value(x) -- the
+// NTT-domain automorphism of a rotation applied by the last pass's store instead of a permutation kernel afterwards
 static void ks_moddown(Context& c, int level, u64* acc, long long s_acc, u64* conv, u64* p, long long sp, const u64* base,
-                       long long sbase, int base_rpp, int base_polys, int nb, hipStream_t s, const KsRescale* rs, bool coeff_out) {
+                       long long sbase, int base_rpp, int base_polys, int nb, hipStream_t s, const KsRescale* rs, bool coeff_out,
+                       const u32* scatter) {
+    LSA_REQUIRE(!scatter || (c.fuse_tails && !rs && !coeff_out), "scattered ModDown store: fused tails, no rescale, NTT-domain output");
     const long long N = c.n;
     const int L = level + 1, np = c.np, T = L + np;
     const long long s_conv = 2LL * L * N;
@@ -265,6 +270,7 @@ static void ks_moddown(Context& c, int level, u64* acc, long long s_acc, u64* co
         fz.out = p;
         fz.out_stride = sp;
         fz.out_rpp = L;
+        fz.scatter = scatter;
         launch_ntt(c, conv, conv, nb, s_conv, s_conv, 2 * L, rm_seq(L), false, s, &fz);
     } else {
         launch_ntt(c, conv, conv, nb, s_conv, 2 * L, rm_seq(L), false, s);
@@ -287,10 +293,26 @@ static bool ks_fuse_mac(const Context& c, int level, const Key& key) {
 }
 static void key_switch(Context& c, int level, const u64* cx, long long scx, const Key& key, u64* p, long long sp,
                        const u64* base, long long sbase, int base_rpp, int base_polys, int nb, u64* ws, hipStream_t s,
-                       const KsRescale* rs = nullptr) {
+                       const KsRescale* rs = nullptr, const u32* scatter = nullptr) {
     const bool fuse = ks_fuse_mac(c, level, key);
     ks_decompose(c, level, cx, scx, nb, ws, s, nullptr, 0, !fuse);
-    ks_finish(c, level, cx, scx, key, p, sp, base, sbase, base_rpp, base_polys, nb, ws, s, rs, false, fuse);
+    ks_finish(c, level, cx, scx, key, p, sp, base, sbase, base_rpp, base_polys, nb, ws, s, rs, false, fuse, scatter);
+}
+
+// the automorphism X -> X^g of a rotation as the SCATTER map of the key switch's last store: out[i] = in[perm_g[i]] is
+// out[perm_{g^-1}[x]] = in[x] (the maps of g and g^-1 are inverse permutations).  Null when the store cannot take it
+// (unfused tails, LSA_ROT_SCATTER=0): the caller then permutes afterwards.
+static const u32* rotation_scatter(Context& c, u64 g) {
+    static const bool on = [] {
+        const char* e = std::getenv("LSA_ROT_SCATTER");
+        return !(e && e[0] == '0');
+    }();
+    if (!on || !c.fuse_tails) return nullptr;
+    const u64 mask = 2 * (u64)c.n - 1;
+    u64 inv = g;   // Newton iteration for the inverse modulo a power of two: doubles the correct low bits each step
+    for (int i = 0; i < 6; i++) inv = (inv * (2 - g * inv)) & mask;
+    LSA_REQUIRE(((inv * g) & mask) == 1, "Galois element without an inverse");
+    return c.ntt_perm(inv);
 }
 
 // ------------------------------------------------------------------------------------------------ rescale
@@ -401,9 +423,19 @@ void ckks_rotate(Context& c, int level, const u64* in, u64 g, const Key& glk, u6
                  long long sout, hipStream_t s) {
     const long long N = c.n;
     const int L = level + 1;
-    const u32* perm = c.ntt_perm(g);
     const size_t ks_rows = ks_ws_rows(c, level);
     const long long sp = 2LL * L * N;
+    // (an in-place rotation keeps the two-step form: the tail reads c0 from `in` while other workgroups already store)
+    const bool apart = out + (size_t)batch * sout <= in || in + (size_t)batch * sin <= out;
+    if (const u32* scatter = apart ? rotation_scatter(c, g) : nullptr) {
+        // the permutation rides on the ModDown tail's store: no intermediate, no permutation kernel (2L reads + 2L writes less)
+        for_tiles(c, ks_rows, batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
+            const u64* ct = in + (size_t)b0 * sin;
+            key_switch(c, level, ct + (long long)L * N, sin, glk, out + (size_t)b0 * sout, sout, ct, sin, L, 1, nb, ws, st, nullptr, scatter);
+        });
+        return;
+    }
+    const u32* perm = c.ntt_perm(g);
     for_tiles(c, ks_rows + 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
         u64* p = ws + ks_rows * N * tb;
         const u64* ct = in + (size_t)b0 * sin;
@@ -421,13 +453,22 @@ void ckks_rotate_many(Context& c, int level, const u64* in, int n_rot, const u64
     const int L = level + 1;
     const size_t ks_rows = ks_ws_rows(c, level);
     const long long sp = 2LL * L * N;
-    std::vector<const u32*> perms(n_rot);
-    for (int i = 0; i < n_rot; i++) perms[i] = c.ntt_perm(g[i]);
+    std::vector<const u32*> perms(n_rot), scatters(n_rot);
+    for (int i = 0; i < n_rot; i++) {
+        const bool apart = outs[i] + (size_t)batch * sout <= in || in + (size_t)batch * sin <= outs[i];
+        scatters[i] = apart ? rotation_scatter(c, g[i]) : nullptr;
+        perms[i] = scatters[i] ? nullptr : c.ntt_perm(g[i]);
+    }
     for_tiles(c, ks_rows + 2 * (size_t)L, batch, s, [&](int nb, int b0, u64* ws, int tb, hipStream_t st) {
         u64* p = ws + ks_rows * N * tb;
         const u64* ct = in + (size_t)b0 * sin;
         ks_decompose(c, level, ct + (long long)L * N, sin, nb, ws, st);
         for (int i = 0; i < n_rot; i++) {
+            if (scatters[i]) {   // the permutation rides on the ModDown tail's store
+                ks_finish(c, level, ct + (long long)L * N, sin, *glk[i], outs[i] + (size_t)b0 * sout, sout, ct, sin, L, 1, nb, ws, st, nullptr,
+                          false, false, scatters[i]);
+                continue;
+            }
             ks_finish(c, level, ct + (long long)L * N, sin, *glk[i], p, sp, ct, sin, L, 1, nb, ws, st, nullptr);
             launch_permute_ntt(c, perms[i], p, sp, outs[i] + (size_t)b0 * sout, sout, 2 * L, nb, st);
         }
