@@ -1140,13 +1140,20 @@ struct KsMacArgs {
     int logn, L, np, nq, beta, kcomp, klvl, batch, bpt;
     int n_tl;                      // 0: every target limb; else the launch covers tl_list[0..n_tl)
     unsigned char tl_list[64];
+    // EXT (k_ks_mac<KB, true>): the product leaves as a ROTATED EXTENDED ciphertext instead of the plain accumulator --
+    // acc[b][h][tl][scatter[x]] = sum(x) + (h == 0 and tl < L ? P * base[b][tl][x] : 0): the gadget product, the c0 * P term and
+    // the automorphism of a baby-step rotation in one pass (otherwise k_permute_ext re-reads and re-writes 2(L+k) limbs)
+    const unsigned* scatter;
+    const u64* base;
+    const u64* pm;                 // [L] P mod q_j, Montgomery form
+    long long sbase;
 };
 
 // grid: x = T * (N/2/TPB), y = groups of `bpt` batch items.  The key is in Montgomery form, so sum_d ext_d*key_d needs
 // ONE REDC per output.  A thread keeps its 2*beta key words in registers and walks `bpt` ciphertexts with them: the key
 // (68 MiB at the headline shape) is then streamed once per group instead of once per ciphertext.
 // KB = number of digits whose key words are register-resident (0: stream the key per ciphertext)
-template <int KB>
+template <int KB, bool EXT = false>
 __global__ __launch_bounds__(TPB) void k_ks_mac(KsMacArgs g) {
     const int chunks = (1 << g.logn) / (2 * TPB);
     const int tl = g.n_tl ? g.tl_list[blockIdx.x / chunks] : blockIdx.x / chunks;
@@ -1233,6 +1240,21 @@ __global__ __launch_bounds__(TPB) void k_ks_mac(KsMacArgs g) {
         r10 = add_mod(r10, csub(mont_redc_lazy(h10, l10, m.q, m.qinv), m.q), m.q);
         r11 = add_mod(r11, csub(mont_redc_lazy(h11, l11, m.q, m.qinv), m.q), m.q);
 #endif
+        if constexpr (EXT) {
+            if (tl < g.L) {
+                const ulonglong2 c0 = ld2(g.base + b * g.sbase + tl * N + x);
+                const u64 k = g.pm[tl];
+                r00 = add_mod(r00, mont_mul(c0.x, k, m.q, m.qinv), m.q);
+                r01 = add_mod(r01, mont_mul(c0.y, k, m.q, m.qinv), m.q);
+            }
+            const uint2 sx = *reinterpret_cast<const uint2*>(g.scatter + x);
+            u64* po = g.acc + b * g.sacc + tl * N;
+            po[sx.x] = r00;
+            po[sx.y] = r01;
+            po[(long long)T * N + sx.x] = r10;
+            po[(long long)T * N + sx.y] = r11;
+            continue;
+        }
         u64* pa = g.acc + b * g.sacc + tl * N + x;
 #if defined(LSA_KS_DIAG_NO_STORE)
         if (r00 == 0x123456789abcdefull) st2(pa, r00, r01);
@@ -1244,10 +1266,41 @@ __global__ __launch_bounds__(TPB) void k_ks_mac(KsMacArgs g) {
     }
 }
 
+template <bool EXT>
+static void launch_ks_mac_kb(int beta, dim3 grid, hipStream_t s, const KsMacArgs& g) {
+    // the register-resident key costs 8 VGPRs per digit slot: 5 and 6 digits (the 25Q+5P chains) get their own instantiations
+    // instead of the 8-slot one (182 VGPRs, 2 waves per SIMD)
+    if (beta <= 2) hipLaunchKernelGGL((k_ks_mac<2, EXT>), grid, dim3(TPB), 0, s, g);   // low levels: 86 VGPRs, 5 waves per SIMD
+    else if (beta <= 4) hipLaunchKernelGGL((k_ks_mac<4, EXT>), grid, dim3(TPB), 0, s, g);
+    else if (beta <= 5) hipLaunchKernelGGL((k_ks_mac<5, EXT>), grid, dim3(TPB), 0, s, g);
+    else if (beta <= 6) hipLaunchKernelGGL((k_ks_mac<6, EXT>), grid, dim3(TPB), 0, s, g);
+    else if (beta <= 8) hipLaunchKernelGGL((k_ks_mac<8, EXT>), grid, dim3(TPB), 0, s, g);
+    else hipLaunchKernelGGL((k_ks_mac<0, EXT>), grid, dim3(TPB), 0, s, g);
+}
+
+// scatter (with engine < 0): the result is written as the rotated extended ciphertext perm(acc + P * c0) -- scatter = the index
+// map of the rotation's inverse element, base = the ciphertext whose c0 enters (see KsMacArgs)
 void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext, const Key& key,
-                   u64* acc, long long sacc, int batch, hipStream_t s, int engine) {
+                   u64* acc, long long sacc, int batch, hipStream_t s, int engine, const u32* scatter, const u64* base, long long sbase) {
     if (batch <= 0) return;
     KsMacArgs g{};
+    LSA_REQUIRE(!scatter || (engine < 0 && base), "key MAC: the extended output covers every target limb and needs the ciphertext");
+    if (scatter) {
+        const int L = level + 1;
+        std::vector<int> mods(L);
+        std::vector<u64> pm(L);
+        for (int j = 0; j < L; j++) {
+            mods[j] = j;
+            const u64 q = c.T.mod[j];
+            u64 pr = 1;
+            for (int l = 0; l < c.np; l++) pr = mul_mod_host(pr, c.T.mod[c.p_mod(l)] % q, q);
+            pm[j] = pr;
+        }
+        g.pm = c.const_vec("pmodq" + std::to_string(L), mods, pm);
+        g.scatter = scatter;
+        g.base = base;
+        g.sbase = sbase;
+    }
     g.cx = cx;
     g.ext = ext;
     g.key = key.data;
@@ -1276,21 +1329,15 @@ void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u6
         targets = g.n_tl;
     }
     const double T = targets;
-    ProfScope ps(c, PROF_KSMAC, 8.0 * c.n * (batch * (g.beta * T + 2 * T) + 2.0 * g.beta * T), s);
+    ProfScope ps(c, PROF_KSMAC, 8.0 * c.n * (batch * (g.beta * T + 2 * T + (scatter ? g.L : 0)) + 2.0 * g.beta * T), s);
     // enough workgroups to fill the chip, as few key re-reads as possible
     const dim3 grid1 = ew_grid(c, targets, 1);
     const int groups = std::max(1, std::min(batch, (int)((2048 + grid1.x - 1) / grid1.x)));
     g.batch = batch;
     g.bpt = (batch + groups - 1) / groups;
     const dim3 grid(grid1.x, (unsigned)((batch + g.bpt - 1) / g.bpt));
-    // the register-resident key costs 8 VGPRs per digit slot: 5 and 6 digits (the 25Q+5P chains) get their own instantiations
-    // instead of the 8-slot one (182 VGPRs, 2 waves per SIMD)
-    if (g.beta <= 2) hipLaunchKernelGGL(k_ks_mac<2>, grid, dim3(TPB), 0, s, g);   // low levels: 86 VGPRs, 5 waves per SIMD
-    else if (g.beta <= 4) hipLaunchKernelGGL(k_ks_mac<4>, grid, dim3(TPB), 0, s, g);
-    else if (g.beta <= 5) hipLaunchKernelGGL(k_ks_mac<5>, grid, dim3(TPB), 0, s, g);
-    else if (g.beta <= 6) hipLaunchKernelGGL(k_ks_mac<6>, grid, dim3(TPB), 0, s, g);
-    else if (g.beta <= 8) hipLaunchKernelGGL(k_ks_mac<8>, grid, dim3(TPB), 0, s, g);
-    else hipLaunchKernelGGL(k_ks_mac<0>, grid, dim3(TPB), 0, s, g);
+    if (scatter) launch_ks_mac_kb<true>(g.beta, grid, s, g);
+    else launch_ks_mac_kb<false>(g.beta, grid, s, g);
     LSA_HIP(hipGetLastError());
 }
 

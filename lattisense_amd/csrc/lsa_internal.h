@@ -257,8 +257,11 @@ void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows
                      long long ssrc, long long sdst, hipStream_t s);
 // key-switch inner product: acc[h][tl] = sum_d ext(d,tl) * key[d][h][tl];  ext(d,tl) = cx[tl] when tl is in digit d
 // engine: -1 every target limb; 0 / 1 only the target limbs of the integer / FP64 butterfly engine
+// scatter (engine -1 only): the result leaves as the ROTATED EXTENDED ciphertext acc[h][tl][scatter[x]] = sum(x) + (h == 0, tl < L:
+// P * base[tl][x]) -- gadget product, c0 * P and the automorphism of a baby-step rotation in one pass
 void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u64* ext, long long sext,
-                   const Key& key, u64* acc, long long sacc, int batch, hipStream_t s, int engine = -1);
+                   const Key& key, u64* acc, long long sacc, int batch, hipStream_t s, int engine = -1,
+                   const u32* scatter = nullptr, const u64* base = nullptr, long long sbase = 0);
 // out[h][i] = base[h][i] + (acc[h][i] - conv[h][i]) * Pinv_i       (base may be null)
 void launch_moddown_final(Context& c, int level, const u64* acc, long long sacc, int acc_rows_per_poly, const u64* conv,
                           long long sconv, const u64* base, long long sbase, int base_rows_per_poly, int base_polys,

@@ -302,17 +302,22 @@ static void key_switch(Context& c, int level, const u64* cx, long long scx, cons
 // the automorphism X -> X^g of a rotation as the SCATTER map of the key switch's last store: out[i] = in[perm_g[i]] is
 // out[perm_{g^-1}[x]] = in[x] (the maps of g and g^-1 are inverse permutations).  Null when the store cannot take it
 // (unfused tails, LSA_ROT_SCATTER=0): the caller then permutes afterwards.
-static const u32* rotation_scatter(Context& c, u64 g) {
+static bool rotation_scatter_on() {
     static const bool on = [] {
         const char* e = std::getenv("LSA_ROT_SCATTER");
         return !(e && e[0] == '0');
     }();
-    if (!on || !c.fuse_tails) return nullptr;
+    return on;
+}
+static const u32* inverse_perm(Context& c, u64 g) {
     const u64 mask = 2 * (u64)c.n - 1;
     u64 inv = g;   // Newton iteration for the inverse modulo a power of two: doubles the correct low bits each step
     for (int i = 0; i < 6; i++) inv = (inv * (2 - g * inv)) & mask;
     LSA_REQUIRE(((inv * g) & mask) == 1, "Galois element without an inverse");
     return c.ntt_perm(inv);
+}
+static const u32* rotation_scatter(Context& c, u64 g) {
+    return rotation_scatter_on() && c.fuse_tails ? inverse_perm(c, g) : nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------ rescale
@@ -489,13 +494,19 @@ void ckks_rotate_many_ext(Context& c, int level, const u64* in, int n_rot, const
     if (n_rot <= 0) return;
     const long long N = c.n;
     const int L = level + 1;
+    const bool one_pass = rotation_scatter_on();   // the MAC writes the rotated extended ciphertext itself (LSA_ROT_SCATTER=0: MAC, then k_permute_ext)
     std::vector<const u32*> perms(n_rot);
-    for (int i = 0; i < n_rot; i++) perms[i] = c.ntt_perm(g[i]);
+    for (int i = 0; i < n_rot; i++) perms[i] = one_pass ? inverse_perm(c, g[i]) : c.ntt_perm(g[i]);
     for_tiles(c, ks_ws_rows(c, level), batch, s, [&](int nb, int b0, u64* ws, int, hipStream_t st) {
         const u64* ct = in + (size_t)b0 * sin;
         const KsWorkspace w = ks_layout(c, level, nb, ws);
         ks_decompose(c, level, ct + (long long)L * N, sin, nb, ws, st);
         for (int i = 0; i < n_rot; i++) {
+            if (one_pass) {
+                launch_ks_mac(c, level, ct + (long long)L * N, sin, w.ext, w.s_ext, *glk[i], outs[i] + (size_t)b0 * sout, sout, nb, st, -1,
+                              perms[i], ct, sin);
+                continue;
+            }
             ks_mac(c, level, ct + (long long)L * N, sin, *glk[i], nb, ws, st, false);
             launch_permute_ext(c, level, perms[i], w.acc, w.s_acc, ct, sin, 1, outs[i] + (size_t)b0 * sout, sout, false, nb, st);
         }
