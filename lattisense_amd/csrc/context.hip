@@ -156,9 +156,15 @@ u64* Context::workspace2(size_t words, hipStream_t s) {
 }
 
 const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered,
-                                      bool pinv_scaled) {
+                                      bool pinv_scaled, const BaseConvFold* fold) {
     std::string key = centered ? "c" : "u";
     if (pinv_scaled) key += "s";
+    if (fold) {
+        LSA_REQUIRE(!fold->tag.empty() && (fold->src_pre.empty() || fold->src_pre.size() == src.size()) &&
+                        (fold->dst_scale.empty() || fold->dst_scale.size() == dst.size()),
+                    "base conversion: folded factors do not match the limb lists");
+        key += "f:" + fold->tag;
+    }
     for (int x : src) key += "|" + std::to_string(x);
     key += "->";
     for (int x : dst) key += "|" + std::to_string(x);
@@ -179,6 +185,13 @@ const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::ve
             if (l != i) pr = mul_mod_host(pr, T.mod[src[l]] % qi, qi);
         K->shat_inv_m[i] = to_mont_host(inv_mod(pr, qi), qi);
         K->half_src[i] = mul_mod_host(qi - 1, (qi + 1) >> 1, qi);  // floor(S/2) mod q_i with S == 0 mod q_i, S odd
+        if (fold && !fold->src_pre.empty()) {
+            // y_i = (x * f + half) * shat_inv = (x + half * f^-1) * (f * shat_inv): the kernel's add-then-multiply shape is kept
+            const u64 f = fold->src_pre[i] % qi;
+            LSA_REQUIRE(f != 0, "base conversion: folded source factor is zero");
+            K->shat_inv_m[i] = to_mont_host(mul_mod_host(inv_mod(pr, qi), f, qi), qi);
+            K->half_src[i] = mul_mod_host(K->half_src[i], inv_mod(f, qi), qi);
+        }
         K->qf[i] = (double)qi;
         K->rf[i] = 1.0 / (double)qi;
     }
@@ -193,6 +206,7 @@ const BaseConvPlan* Context::baseconv(const std::vector<int>& src, const std::ve
             for (int l = 0; l < np; l++) pp = mul_mod_host(pp, T.mod[p_mod(l)] % pj, pj);
             scale = inv_mod(pp, pj);
         }
+        if (fold && !fold->dst_scale.empty()) scale = mul_mod_host(scale, fold->dst_scale[j] % pj, pj);
         for (int i = 0; i < ns; i++) {
             u64 pr = 1 % pj;
             for (int l = 0; l < ns; l++)

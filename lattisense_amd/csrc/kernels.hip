@@ -914,6 +914,9 @@ struct BaseConvArgs {
     long long ssrc, sdst;
     int logn;
     BaseConvRows rows;
+    const u64* sub;   // optional: the converted value is src - sub (limb i of sub at row sub_row[i], batch stride ssub)
+    long long ssub;
+    int sub_row[LSA_BC_MAX_SRC];
 };
 
 // NSMAX = compile-time bound of the source-limb loops (registers for y[] scale with it; dispatched from ns); EXACT: ns ==
@@ -951,6 +954,17 @@ __global__ __launch_bounds__(TPB) void k_baseconv(BaseConvArgs g) {
 #pragma unroll
     for (int i = 0; i < NSMAX; i++)
         if (EXACT || i < ns) xin[i] = ld2(src + ((long long)g.rows.src_row[i] << g.logn));
+    if (g.sub) {   // block-uniform: a branch around the loop, only the launches that fold a subtraction take it
+        const u64* sub = g.sub + b * g.ssub + x;
+#pragma unroll
+        for (int i = 0; i < NSMAX; i++)
+            if (EXACT || i < ns) {
+                const u64 q = mods_c[K.src_mod[i]].q;
+                const ulonglong2 w = ld2(sub + ((long long)g.sub_row[i] << g.logn));
+                xin[i].x = sub_mod(xin[i].x, w.x, q);
+                xin[i].y = sub_mod(xin[i].y, w.y, q);
+            }
+    }
     u64 y[NSMAX][2];
     double vf0 = 0.0, vf1 = 0.0;
 #pragma unroll
@@ -1104,9 +1118,14 @@ static void launch_baseconv_ns(int ns, int nd, bool split, dim3 grid, hipStream_
 }
 
 void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
-                     long long ssrc, long long sdst, hipStream_t s) {
+                     long long ssrc, long long sdst, hipStream_t s, const u64* sub, long long ssub, const int* sub_row) {
     if (batch <= 0) return;
     BaseConvArgs g{};
+    g.sub = sub;
+    g.ssub = ssub;
+    LSA_REQUIRE(!sub || sub_row, "base conversion: subtrahend rows missing");
+    if (sub)
+        for (int i = 0; i < k->ns; i++) g.sub_row[i] = sub_row[i];
     g.k = k->dev;
     g.mods = c.d_mods;
     g.src = src;
@@ -1115,7 +1134,7 @@ void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows
     g.sdst = sdst;
     g.logn = c.logn;
     g.rows = rows;
-    ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns + k->nd), s);
+    ProfScope ps(c, PROF_BASECONV, 8.0 * c.n * batch * (double)(k->ns * (sub ? 2 : 1) + k->nd), s);
     const dim3 grid((unsigned)(c.n / (2 * TPB)), (unsigned)batch, 1);
     const int ns = k->ns, nd = k->nd;
     if (ns <= 1) launch_baseconv_ns<1>(ns, nd, k->split29, grid, s, g);

@@ -144,8 +144,15 @@ struct Context {
     int p_mod(int i) const { return nq + i; }
     int aux_mod(int i) const { return nq + np + i; }
     // pinv_scaled: the outputs of every target but the last are multiplied by P^-1 mod p_j (merged ModDown + rescale)
+    // fold: element-wise steps on either side of a conversion folded into its constants (both linear, so the residues are the
+    // ones the separate steps give): src_pre[i] multiplies source limb i BEFORE the conversion (the centring offset and
+    // (S/q_i)^-1 absorb it), dst_scale[j] multiplies target j's output; `tag` names the variant in the plan cache
+    struct BaseConvFold {
+        std::string tag;
+        std::vector<u64> src_pre, dst_scale;   // plain residues; empty = none
+    };
     const BaseConvPlan* baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered,
-                                 bool pinv_scaled = false);
+                                 bool pinv_scaled = false, const BaseConvFold* fold = nullptr);
     const u64* pinv_vec(int level);
     const u64* qlinv_vec(int level);
     const u32* ntt_perm(u64 g);
@@ -253,8 +260,11 @@ struct BaseConvRows {
     int src_row[LSA_BC_MAX_SRC];
     int dst_row[LSA_BC_MAX_DST];
 };
+// sub (optional): converted is src - sub, limb for limb (rows.src_row indexes both; its own batch stride and row offsets
+// sub_row) -- the subtraction of a preceding element-wise step done on the conversion's source load
 void launch_baseconv(Context& c, const BaseConvPlan* k, const BaseConvRows& rows, const u64* src, u64* dst, int batch,
-                     long long ssrc, long long sdst, hipStream_t s);
+                     long long ssrc, long long sdst, hipStream_t s, const u64* sub = nullptr, long long ssub = 0,
+                     const int* sub_row = nullptr);
 // key-switch inner product: acc[h][tl] = sum_d ext(d,tl) * key[d][h][tl];  ext(d,tl) = cx[tl] when tl is in digit d
 // engine: -1 every target limb; 0 / 1 only the target limbs of the integer / FP64 butterfly engine
 // scatter (engine -1 only): the result leaves as the ROTATED EXTENDED ciphertext acc[h][tl][scatter[x]] = sum(x) + (h == 0, tl < L:

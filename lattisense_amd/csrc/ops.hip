@@ -619,6 +619,13 @@ void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int ba
         amods.push_back(c.aux_mod(i));
         rmT.mod_of[L + i] = (unsigned char)c.aux_mod(i);
     }
+    // folded (default; LSA_BFV_FOLD=0: the separate element-wise steps): the Q limbs are transformed straight from the operands into
+    // the extended buffer (no copy), and the two element-wise steps around the last conversion -- (aux - ext) * Q^-1 before it,
+    // * t after it -- live in its source load and its constants (Context::BaseConvFold)
+    static const bool fold_on = [] {
+        const char* e = std::getenv("LSA_BFV_FOLD");
+        return !(e && e[0] == '0');
+    }();
     const BaseConvPlan* kQA = c.baseconv(qmods, amods, true);
     const BaseConvPlan* kAQ = c.baseconv(amods, qmods, true);
     BaseConvRows rQA{}, rAQ{};
@@ -641,6 +648,12 @@ void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int ba
     }
     const u64* kQinv = c.const_vec("bfv_qinv" + std::to_string(L), amods, qinv);
     const u64* kT = c.const_vec("bfv_t" + std::to_string(L), qmods, tq);
+    Context::BaseConvFold fold{"bfv_mul" + std::to_string(L), qinv, tq};
+    const BaseConvPlan* kAQf = fold_on ? c.baseconv(amods, qmods, true, false, &fold) : nullptr;
+    std::vector<int> sub_rows(M);
+    for (int i = 0; i < M; i++) sub_rows[i] = i;
+    RowMap rmAux = rmT;   // the auxiliary rows only
+    for (int i = 0; i < L; i++) rmAux.mod_of[i] = LSA_ROW_SKIP;
 
     for_tiles(c, rows, batch, s0, [&](int nb, int b0, u64* ws, int tb, hipStream_t s) {
         u64* ea = ws;
@@ -653,23 +666,31 @@ void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int ba
         const int nops = (a == b && sa == sb) ? 1 : 2;
         for (int o = 0; o < nops; o++) {
             for (int p = 0; p < 2; p++) {
-                // Q limbs copied, aux limbs by centred exact extension
+                // Q limbs copied (folded: transformed from where they are), aux limbs by centred exact extension
                 std::vector<int> rr(L);
                 for (int i = 0; i < L; i++) rr[i] = p * L + i;
-                launch_copy_rows(c, srcs[o], ss[o], es[o] + (size_t)p * T2 * N, s_e, L, rr.data(), nb, s);
+                if (fold_on) launch_ntt(c, srcs[o] + (size_t)p * L * N, es[o] + (size_t)p * T2 * N, nb, ss[o], s_e, L, rm_seq(L), false, s);
+                else launch_copy_rows(c, srcs[o], ss[o], es[o] + (size_t)p * T2 * N, s_e, L, rr.data(), nb, s);
                 launch_baseconv(c, kQA, rQA, srcs[o] + (size_t)p * L * N, es[o] + ((size_t)p * T2 + L) * N, nb, ss[o],
                                 s_e, s);
             }
-            launch_ntt(c, es[o], es[o], nb, s_e, 2 * T2, rmT, false, s);
+            launch_ntt(c, es[o], es[o], nb, s_e, 2 * T2, fold_on ? rmAux : rmT, false, s);
         }
         launch_tensor(c, ea, nops == 1 ? ea : eb, d, nb, s_e, s_e, s_d, T2, rmT, s);
         launch_ntt(c, d, d, nb, s_d, 3 * T2, rmT, true, s);
         for (int k = 0; k < 3; k++)
             launch_baseconv(c, kQA, rQA, d + (size_t)k * T2 * N, ext + (size_t)k * M * N, nb, s_d, s_x, s);
+        u64* o3 = d3 + (size_t)b0 * sd;
+        if (fold_on) {
+            // out = t * conv_{A->Q}((aux - ext) * Q^-1): the subtraction on the conversion's source load, both factors in its constants
+            for (int k = 0; k < 3; k++)
+                launch_baseconv(c, kAQf, rAQ, d + ((size_t)k * T2 + L) * N, o3 + (size_t)k * L * N, nb, s_d, sd, s, ext + (size_t)k * M * N,
+                                s_x, sub_rows.data());
+            return;
+        }
         // aux part <- (aux - ext) * Q^-1     (= round(d/Q) in basis QMul)
         launch_sub_mul_general(c, 3, M, lmA, kQinv, d + (size_t)L * N, s_d, T2, ext, s_x, M, nullptr, 0, 0, 0,
                                d + (size_t)L * N, s_d, T2, nb, s);
-        u64* o3 = d3 + (size_t)b0 * sd;
         for (int k = 0; k < 3; k++)
             launch_baseconv(c, kAQ, rAQ, d + ((size_t)k * T2 + L) * N, o3 + (size_t)k * L * N, nb, s_d, sd, s);
         launch_sub_mul_general(c, 3, L, lmQ, kT, o3, sd, L, nullptr, 0, 0, nullptr, 0, 0, 0, o3, sd, L, nb, s);
