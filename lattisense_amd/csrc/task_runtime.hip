@@ -15,6 +15,7 @@
 //   * every failure is turned into a non-zero return code + lsa_last_error(); nothing throws across extern "C".
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <future>
 #include <optional>
@@ -160,24 +161,95 @@ static void stream_copy(u64* dst, const u64* src, size_t words) {
 static void stream_copy(u64* dst, const u64* src, size_t words) { memcpy(dst, src, words * sizeof(u64)); }
 #endif
 
-// static-chunk parallel loop on a few host threads (memcpy-bound staging work)
-template <typename F> void parallel_for(size_t n, F&& fn) {
-    if (n == 0) return;
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({n, (size_t)std::max(1, std::min(16, hw > 0 ? hw : 1) - 2), 14}));
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= n) return;
-            fn(i);
+// Parallel loop on a few PERSISTENT host threads (memcpy-bound staging work; the staging loop calls this once per 32 MiB of
+// input).  One loop at a time (callers on different shard threads queue on `run_mu_`).  LSA_STAGE_THREADS overrides the count.
+// Measured (profiles/r03/t2_staging_and_lane_handback.log): the copies themselves bound the CKKS x64 graph -- 208 MiB per chunk
+// staged at ~55 GB/s read + 55 GB/s written on the box's 16-core share while the DMA engine reads the previous 32 MiB --, not the
+// thread start-up (this pool against a spawn per call: no change) and not the lane turnaround (handing a lane back before its
+// chunk's import: no change either).
+class StagePool {
+  public:
+    static StagePool& get() {
+        static StagePool p;
+        return p;
+    }
+    template <typename F> void run(size_t n, F&& fn) {
+        if (n == 0) return;
+        if (workers_.empty() || n == 1) {
+            for (size_t i = 0; i < n; i++) fn(i);
+            return;
         }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; t++) pool.emplace_back(worker);
-    worker();
-    for (auto& t : pool) t.join();
-}
+        std::lock_guard<std::mutex> one(run_mu_);
+        std::function<void(size_t)> f = std::ref(fn);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &f;
+            n_ = n;
+            next_.store(0);
+            active_ = (int)workers_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        work(f, n);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return active_ == 0; });   // every worker has seen this generation and left work()
+        fn_ = nullptr;
+    }
+    ~StagePool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+
+  private:
+    StagePool() {
+        const int hw = (int)std::thread::hardware_concurrency();
+        int nthreads = std::max(1, std::min(16, hw > 0 ? hw : 1) - 2);
+        if (const char* e = std::getenv("LSA_STAGE_THREADS")) nthreads = std::max(1, std::atoi(e));
+        nthreads = std::min(nthreads, 32);
+        for (int t = 1; t < nthreads; t++) workers_.emplace_back([this] { loop(); });
+    }
+    void work(const std::function<void(size_t)>& f, size_t n) {
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= n) return;
+            f(i);
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* f;
+            size_t n;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                f = fn_;
+                n = n_;
+            }
+            work(*f, n);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--active_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0;
+    std::atomic<size_t> next_{0};
+    int active_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+template <typename F> void parallel_for(size_t n, F&& fn) { StagePool::get().run(n, fn); }
 
 struct DevDatum {  // a ciphertext or plaintext living in (a slice of) a slab: [polys][level+1][N]
     std::shared_ptr<Slab> slab;
