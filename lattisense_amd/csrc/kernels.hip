@@ -271,10 +271,8 @@ __global__ __launch_bounds__(LSA_R16_THREADS, FP ? LSA_KSMAC_WAVES_FP : LSA_KSMA
 }
 
 bool ks_fused_enabled(const Context& c) {
-    static const bool on = [] {
-        const char* e = getenv("LSA_KS_FUSED");
-        return !(e && e[0] == '0');
-    }();
+    const char* e = getenv("LSA_KS_FUSED");   // read per call: the parity tests flip it inside one process (a key uploaded either
+    const bool on = !(e && e[0] == '0');      // way works with either setting: the fused path needs key.fp and is skipped without it)
     if (!on || c.plan.npass != 2 || !c.fp_raw) return false;
     const NttPassShape& p = c.plan.pass[1];
     return p.tau == 12 && p.lambda == 0 && (p.mu == 7 || p.mu == 8) && p.s_lo == c.logn - p.mu;
@@ -336,10 +334,8 @@ bool launch_ntt_ksmac(Context& c, int level, const u64* cx, long long scx, u64* 
         if (!g.n_tl) continue;
         const long long nblocks = (long long)batch * g.n_tl * (1 << (c.logn - 12));
         LSA_REQUIRE(nblocks < (1LL << 31), "ntt: grid too large");
-        static const bool xcd = [] {
-            const char* e = getenv("LSA_KSMAC_XCD");   // =0: plain batch-fastest order (A/B: +0.45 % headline with the deal, ab_ksmac_xcd_deal.log)
-            return !(e && e[0] == '0');
-        }();
+        const char* xcd_env = getenv("LSA_KSMAC_XCD");   // =0: plain batch-fastest order (A/B: +0.45 % headline with the deal, ab_ksmac_xcd_deal.log)
+        const bool xcd = !(xcd_env && xcd_env[0] == '0');
         g.xcd_deal = xcd && ((g.n_tl << (c.logn - 12)) % 8 == 0) ? 1 : 0;
         const double ntt_bytes = 16.0 * c.n * transforms * batch / 2;
         ProfScope ps(c, PROF_NTT, ntt_bytes + 8.0 * c.n * g.n_tl * (batch * ((double)g.beta + 2.0) + 2.0 * g.beta), s, ntt_bytes);

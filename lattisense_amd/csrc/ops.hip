@@ -302,12 +302,9 @@ static void key_switch(Context& c, int level, const u64* cx, long long scx, cons
 // the automorphism X -> X^g of a rotation as the SCATTER map of the key switch's last store: out[i] = in[perm_g[i]] is
 // out[perm_{g^-1}[x]] = in[x] (the maps of g and g^-1 are inverse permutations).  Null when the store cannot take it
 // (unfused tails, LSA_ROT_SCATTER=0): the caller then permutes afterwards.
-static bool rotation_scatter_on() {
-    static const bool on = [] {
-        const char* e = std::getenv("LSA_ROT_SCATTER");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+static bool rotation_scatter_on() {   // read per call (not cached): the parity tests flip it inside one process
+    const char* e = std::getenv("LSA_ROT_SCATTER");
+    return !(e && e[0] == '0');
 }
 static const u32* inverse_perm(Context& c, u64 g) {
     const u64 mask = 2 * (u64)c.n - 1;
@@ -622,10 +619,8 @@ void bfv_mult(Context& c, int level, const u64* a, const u64* b, u64* d3, int ba
     // folded (default; LSA_BFV_FOLD=0: the separate element-wise steps): the Q limbs are transformed straight from the operands into
     // the extended buffer (no copy), and the two element-wise steps around the last conversion -- (aux - ext) * Q^-1 before it,
     // * t after it -- live in its source load and its constants (Context::BaseConvFold)
-    static const bool fold_on = [] {
-        const char* e = std::getenv("LSA_BFV_FOLD");
-        return !(e && e[0] == '0');
-    }();
+    const char* fold_env = std::getenv("LSA_BFV_FOLD");   // read per call: the parity tests flip it inside one process
+    const bool fold_on = !(fold_env && fold_env[0] == '0');
     const BaseConvPlan* kQA = c.baseconv(qmods, amods, true);
     const BaseConvPlan* kAQ = c.baseconv(amods, qmods, true);
     BaseConvRows rQA{}, rAQ{};
