@@ -28,14 +28,17 @@ def _oracle_plains(plan):
     return plan.oracle_plains()
 
 
-@pytest.mark.parametrize("log_n,encapsulate,double_hoist", [(10, False, True), (11, True, True), (10, False, False)])
-def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate, double_hoist, monkeypatch):
+@pytest.mark.parametrize("log_n,encapsulate,double_hoist,scatter", [(10, False, True, True), (11, True, True, True), (10, False, False, True),
+                                                                     (10, False, True, False), (10, False, False, False)])
+def test_bootstrap_bit_exact_against_the_oracle_program(log_n, encapsulate, double_hoist, scatter, monkeypatch):
     """double_hoist (the default): the baby-step / giant-step matrices keep their sums over Q u P and divide by P once per giant
     step and once at the end; False (LSA_BT_DOUBLE_HOIST=0 when the plan is made): one division per rotation.  The oracle
     program follows the plan's choice; either way device == oracle bit for bit."""
     need_gpu()
     if not double_hoist:
         monkeypatch.setenv("LSA_BT_DOUBLE_HOIST", "0")
+    if not scatter:   # rotations as MAC / ModDown + a permutation kernel (k_permute_ext / k_permute) instead of scattered stores
+        monkeypatch.setenv("LSA_ROT_SCATTER", "0")
     from lattisense_amd.device import BootstrapPlan
     from oracle.ckks_bootstrap import Bootstrapper, Ct, Evaluator
     from oracle.client import Client, mean_precision_bits
