@@ -40,6 +40,16 @@ static void emu_block_r16(const NttPassArgs& a, const NttBlockCtx& bc, u64* lds)
         }
 }
 
+// the nine-stage second pass (three radix-8 groups per point, four phases)
+static void emu_block_r8x3(const NttPassArgs& a, const NttBlockCtx& bc, u64* lds) {
+    std::vector<std::array<u64, 16>> regs(LSA_R16_THREADS);
+    for (int phase = 0; phase < 4; phase++)
+        for (int t = 0; t < LSA_R16_THREADS; t++) {
+            u64(&v)[16] = *reinterpret_cast<u64(*)[16]>(regs[t].data());
+            r8x3_phase<3>(a, bc, t, lds, phase, v);
+        }
+}
+
 extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int batch, long long batch_stride, int rows,
                            const unsigned char* mod_of, int period, int inverse, int tau_max, int allow_fp64) {
     const int row_inner = (allow_fp64 >> 1) & 1;   // bit 1: the (tile, row, batch) workgroup order
@@ -91,7 +101,8 @@ extern "C" int lsa_emu_ntt(int n, const u64* moduli, int nmod, u64* data, int ba
             NttBlockCtx bc = ntt_decode_block(a, bid);
             if (bc.mod == LSA_ROW_SKIP) continue;
             if (r16 && ntt_r16_shape_ok(a, plan.npass)) {
-                if (a.lambda && a.mu == 8) emu_block_r16<0, 8>(a, bc, lds.data());
+                if (a.mu == 9) emu_block_r8x3(a, bc, lds.data());
+                else if (a.lambda && a.mu == 8) emu_block_r16<0, 8>(a, bc, lds.data());
                 else if (a.lambda) emu_block_r16<0, 7>(a, bc, lds.data());
                 else if (a.mu == 8) emu_block_r16<1, 8>(a, bc, lds.data());
                 else emu_block_r16<1, 7>(a, bc, lds.data());

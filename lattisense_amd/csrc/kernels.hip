@@ -150,6 +150,22 @@ __global__ __launch_bounds__(LSA_R16_THREADS, (FZ & 1) ? LSA_NTT_WAVES_FUSED : L
     r16_sync<PASS>();
     r16_phase<PASS, FZ, MU>(a, bc, tid, lds, 2, v);
 }
+// the nine-stage second pass (N = 2^17 / 2^18): three radix-8 groups per point, two wave-local LDS exchanges (ntt_r16.h)
+template <int FZ>
+__global__ __launch_bounds__(LSA_R16_THREADS, LSA_R16_WAVES) void k_ntt_r8x3(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const int tid = threadIdx.x;
+    const NttBlockCtx bc = ntt_decode_block(a, (long long)blockIdx.x);
+    if (bc.mod == LSA_ROW_SKIP) return;
+    u64 v[16];
+    r8x3_phase<FZ>(a, bc, tid, lds, 0, v);
+    r16_sync<1>();
+    r8x3_phase<FZ>(a, bc, tid, lds, 1, v);
+    r16_sync<1>();
+    r8x3_phase<FZ>(a, bc, tid, lds, 2, v);
+    r16_sync<1>();
+    r8x3_phase<FZ>(a, bc, tid, lds, 3, v);
+}
 static bool ntt_launch_r16(const NttPassArgs& a, int npass, bool fused, long long nblocks, hipStream_t s) {
     static const bool enabled = [] {
         const char* e = getenv("LSA_NTT_R16");
@@ -177,7 +193,15 @@ static bool ntt_launch_r16(const NttPassArgs& a, int npass, bool fused, long lon
         }
     } else {
         if (pro) return false;
-        if (a.mu == 8) {
+        if (a.mu == 9) {
+            static const bool r8x3_enabled = [] {
+                const char* e = getenv("LSA_NTT_R8X3");   // =0: the nine-stage second pass on the staged kernel (A/B)
+                return !(e && e[0] == '0');
+            }();
+            if (!r8x3_enabled) return false;
+            if (epi) hipLaunchKernelGGL((k_ntt_r8x3<2>), grid, block, lds_bytes, s, a);
+            else hipLaunchKernelGGL((k_ntt_r8x3<0>), grid, block, lds_bytes, s, a);
+        } else if (a.mu == 8) {
             if (epi) hipLaunchKernelGGL((k_ntt_r16<1, 2, 8>), grid, block, lds_bytes, s, a);
             else hipLaunchKernelGGL((k_ntt_r16<1, 0, 8>), grid, block, lds_bytes, s, a);
         } else {
@@ -245,7 +269,7 @@ __global__ __launch_bounds__(LSA_R16_THREADS, FP ? LSA_KSMAC_WAVES_FP : LSA_KSMA
     const int own_d = tl < g.L ? tl / g.np : -1;
     int k, i;
     r16_lane<1, MU>(tid, k, i);
-    const unsigned G1 = r16_G1<1, MU>(bc, k), G2 = (G1 << 4) + ((unsigned)i << (8 - MU));
+    const unsigned G1 = r16_G1<1, MU>(bc, k), G2 = (G1 << 4) + ((unsigned)i << (MU <= 8 ? 8 - MU : 0));   // (G2: 8- and 7-stage passes only)
     u64 acc0[16], acc1[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) acc0[e] = acc1[e] = 0;   // (0 is also +0.0)
@@ -256,12 +280,25 @@ __global__ __launch_bounds__(LSA_R16_THREADS, FP ? LSA_KSMAC_WAVES_FP : LSA_KSMA
             bc.row = d * T + tl;
             u64 v[16];
             r16_load_direct<1, false, 0, MU>(a, bc, tid, v);
-            r16_group<1, 0, MU>(v, a, bc, L, G1);
-            r16_lds_put<1, 0, MU>(tid, lds, v);
-            r16_sync<1>();
-            r16_lds_get<1, 1, MU>(tid, lds, v);
-            r16_group<1, 1, MU>(v, a, bc, L, G2);
-            r16_lds_put<1, 1, MU>(tid, lds, v);
+            if constexpr (MU == 9) {   // nine stages: three radix-8 groups per point, two exchanges (ntt_r16.h)
+                r8x3_group<0>(v, a, bc, L, G1, i);
+                r8x3_put<0>(k, i, lds, v);
+                r16_sync<1>();
+                r8x3_get<1>(k, i, lds, v);
+                r8x3_group<1>(v, a, bc, L, G1, i);
+                r8x3_put<1>(k, i, lds, v);
+                r16_sync<1>();
+                r8x3_get<2>(k, i, lds, v);
+                r8x3_group<2>(v, a, bc, L, G1, i);
+                r8x3_put<2>(k, i, lds, v);
+            } else {
+                r16_group<1, 0, MU>(v, a, bc, L, G1);
+                r16_lds_put<1, 0, MU>(tid, lds, v);
+                r16_sync<1>();
+                r16_lds_get<1, 1, MU>(tid, lds, v);
+                r16_group<1, 1, MU>(v, a, bc, L, G2);
+                r16_lds_put<1, 1, MU>(tid, lds, v);
+            }
             r16_sync<1>();
         }
         r16_mac_digit<MU, FP>(g, a, bc, L, tid, d, kj, own, b, tl, lds, acc0, acc1);
@@ -275,7 +312,7 @@ bool ks_fused_enabled(const Context& c) {
     const bool on = !(e && e[0] == '0');      // way works with either setting: the fused path needs key.fp and is skipped without it)
     if (!on || c.plan.npass != 2 || !c.fp_raw) return false;
     const NttPassShape& p = c.plan.pass[1];
-    return p.tau == 12 && p.lambda == 0 && (p.mu == 7 || p.mu == 8) && p.s_lo == c.logn - p.mu;
+    return p.tau == 12 && p.lambda == 0 && (p.mu == 7 || p.mu == 8 || p.mu == 9) && p.s_lo == c.logn - p.mu;
 }
 
 int ks_fused_engines(const Context& c) {
@@ -340,7 +377,9 @@ bool launch_ntt_ksmac(Context& c, int level, const u64* cx, long long scx, u64* 
         const double ntt_bytes = 16.0 * c.n * transforms * batch / 2;
         ProfScope ps(c, PROF_NTT, ntt_bytes + 8.0 * c.n * g.n_tl * (batch * ((double)g.beta + 2.0) + 2.0 * g.beta), s, ntt_bytes);
         const dim3 grid((unsigned)nblocks), block(LSA_R16_THREADS);
-        if (mu == 8 && eng) hipLaunchKernelGGL((k_ntt_r16_ksmac<8, true>), grid, block, lds_bytes, s, g);
+        if (mu == 9 && eng) hipLaunchKernelGGL((k_ntt_r16_ksmac<9, true>), grid, block, lds_bytes, s, g);
+        else if (mu == 9) hipLaunchKernelGGL((k_ntt_r16_ksmac<9, false>), grid, block, lds_bytes, s, g);
+        else if (mu == 8 && eng) hipLaunchKernelGGL((k_ntt_r16_ksmac<8, true>), grid, block, lds_bytes, s, g);
         else if (mu == 8) hipLaunchKernelGGL((k_ntt_r16_ksmac<8, false>), grid, block, lds_bytes, s, g);
         else if (eng) hipLaunchKernelGGL((k_ntt_r16_ksmac<7, true>), grid, block, lds_bytes, s, g);
         else hipLaunchKernelGGL((k_ntt_r16_ksmac<7, false>), grid, block, lds_bytes, s, g);

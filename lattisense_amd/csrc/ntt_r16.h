@@ -28,8 +28,11 @@
 // MU = 8: a pass of 8 stages = two radix-16 groups per point (N = 2^16 both passes, 2^15 second, 2^17 first);
 // MU = 7: 7 stages = a radix-16 group and a radix-8 group, two of the latter per thread (N = 2^14 both passes, 2^15 first).
 // The twiddle tables are laid out for the plan's radix split (ntt_split): 4 + (MU - 4) for exactly these two.
+// MU = 9 (second pass only: N = 2^17, 2^18): three radix-8 groups per point, see "nine-stage second pass" below.
 LSA_HD bool ntt_r16_shape_ok(const NttPassArgs& a, int npass) {
-    if (npass != 2 || (a.mu != 8 && a.mu != 7) || a.tau != 12) return false;
+    if (npass != 2 || a.tau != 12) return false;
+    if (a.mu == 9) return a.s_lo == a.logn - 9 && a.lambda == 0;
+    if (a.mu != 8 && a.mu != 7) return false;
     return (a.s_lo == 0 && a.lambda == 12 - a.mu) || (a.s_lo == a.logn - a.mu && a.lambda == 0);
 }
 
@@ -434,6 +437,103 @@ LSA_HD void r16_phase(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64*
             r16_lds_get<PASS, 0, MU>(tid, lds, v);
             r16_group<PASS, 0, MU>(v, a, bc, L, G1);
             r16_store_direct<PASS, false, 0, MU>(a, bc, tid, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- nine-stage second pass
+// N = 2^17 / 2^18: the second pass has 9 stages on 512-point chunks, eight per tile.  Same idea with THREE radix-8 groups per
+// point (the plan's split of 9 stages is 3 + 3 + 3: the twiddle tables are laid out for it): lane (k, i), k = tid >> 5 the chunk,
+// i = tid & 31, holds 16 points = two radix-8 groups in each of three register images, exchanged through LDS twice --
+//   image A (stages 0-2, bits 8..6 of the point index vary): points i + 32 E; group g = E & 1 is v[g], v[g + 2], ..  The 32 lanes of a
+//            chunk read 256 contiguous bytes per load instruction, straight from global memory as in the 8-stage pass;
+//   image B (stages 3-5, bits 5..3): points (hi << 6) | (e << 3) | lo with hi = 2 (i >> 3) + g, lo = i & 7, held as v[8 g + e] -- with
+//            the one-word-per-16 padding the 32 lanes of a chunk hit 32 different banks for every (g, e);
+//   image C (stages 6-8, bits 2..0): points 16 i + E, group g = E >> 3 -- the contiguous image the coalesced store / load expects.
+// Both lanes' halves of a chunk sit in one wavefront, so the exchanges stay wave-local (no workgroup barrier).
+template <int IMAGE>
+LSA_HD int r8x3_pt(int i, int E) {
+    if (IMAGE == 0) return i + (E << 5);
+    if (IMAGE == 2) return 16 * i + E;
+    return ((2 * (i >> 3) + (E >> 3)) << 6) | ((E & 7) << 3) | (i & 7);
+}
+// v-index of element e of group g in each image
+template <int IMAGE>
+LSA_HD constexpr int r8x3_slot(int g, int e) {
+    return IMAGE == 0 ? g + 2 * e : 8 * g + e;
+}
+template <int IMAGE>
+LSA_HD void r8x3_group(u64 (&v)[16], const NttPassArgs& a, const NttBlockCtx& bc, const R16Limb& L, unsigned G1, int i) {
+    const int s_base = L.s_lo + 3 * IMAGE;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const unsigned G = IMAGE == 0 ? G1 : IMAGE == 1 ? (G1 << 3) + 2u * (unsigned)(i >> 3) + (unsigned)g : (G1 << 6) + 2u * (unsigned)i + (unsigned)g;
+        if (bc.fp) {
+            double d[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) d[e] = d_from_bits(v[r8x3_slot<IMAGE>(g, e)]);
+            ntt_group_fp<3, false>(d, a.inverse != 0, L.twd, s_base, G, L.q, L.qinv, false, 0.0, 0.0, false);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[r8x3_slot<IMAGE>(g, e)] = d_to_bits(d[e]);
+        } else {
+            u64 w[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) w[e] = v[r8x3_slot<IMAGE>(g, e)];
+            ntt_group_int<3, false>(w, a.inverse != 0, L.tw, s_base, G, L.md.q, false, 0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[r8x3_slot<IMAGE>(g, e)] = w[e];
+        }
+    }
+}
+template <int IMAGE>
+LSA_HD void r8x3_put(int k, int i, u64* lds, const u64 (&v)[16]) {
+#pragma unroll
+    for (int E = 0; E < 16; E++) lds[r16_lds<1, 9>(k, r8x3_pt<IMAGE>(i, E))] = v[E];
+}
+template <int IMAGE>
+LSA_HD void r8x3_get(int k, int i, const u64* lds, u64 (&v)[16]) {
+#pragma unroll
+    for (int E = 0; E < 16; E++) v[E] = lds[r16_lds<1, 9>(k, r8x3_pt<IMAGE>(i, E))];
+}
+// phases (wave-local ordering points between them):
+//   forward: [0] load image A, group A, put | [1] get B, group B, put | [2] get C, group C, put | [3] coalesced store (+ fused epilogue)
+//   inverse: [0] coalesced load -> LDS      | [1] get C, group C, put | [2] get B, group B, put | [3] get A, group A, store image A
+template <int FZ>
+LSA_HD void r8x3_phase(const NttPassArgs& a, const NttBlockCtx& bc, int tid, u64* lds, int phase, u64 (&v)[16]) {
+    const R16Limb L = r16_limb(a, bc);
+    const int k = tid >> 5, i = tid & 31;
+    const unsigned G1 = r16_G1<1, 9>(bc, k);
+    if (!a.inverse) {
+        if (phase == 0) {
+            r16_load_direct<1, false, 0, 9>(a, bc, tid, v);
+            r8x3_group<0>(v, a, bc, L, G1, i);
+            r8x3_put<0>(k, i, lds, v);
+        } else if (phase == 1) {
+            r8x3_get<1>(k, i, lds, v);
+            r8x3_group<1>(v, a, bc, L, G1, i);
+            r8x3_put<1>(k, i, lds, v);
+        } else if (phase == 2) {
+            r8x3_get<2>(k, i, lds, v);
+            r8x3_group<2>(v, a, bc, L, G1, i);
+            r8x3_put<2>(k, i, lds, v);
+        } else {
+            r16_store_coalesced<(FZ & 2) != 0, 9>(a, bc, tid, lds);
+        }
+    } else {
+        if (phase == 0) {
+            r16_load_coalesced<false, 9>(a, bc, tid, lds);
+        } else if (phase == 1) {
+            r8x3_get<2>(k, i, lds, v);
+            r8x3_group<2>(v, a, bc, L, G1, i);
+            r8x3_put<2>(k, i, lds, v);
+        } else if (phase == 2) {
+            r8x3_get<1>(k, i, lds, v);
+            r8x3_group<1>(v, a, bc, L, G1, i);
+            r8x3_put<1>(k, i, lds, v);
+        } else {
+            r8x3_get<0>(k, i, lds, v);
+            r8x3_group<0>(v, a, bc, L, G1, i);
+            r16_store_direct<1, false, 0, 9>(a, bc, tid, v);
         }
     }
 }

@@ -75,8 +75,8 @@ def test_fp64_engine_matches_oracle(emu, logn, tau):
 
 @pytest.mark.parametrize("logn", [14, 15, 16, 17])
 def test_radix16_squared_passes_match_oracle(emu, logn):
-    """the 8- and 7-stage passes of two-pass plans through ntt_r16.h (both passes at N = 2^14 .. 2^16, the first at 2^17 -- its
-    9-stage second pass stays on the staged kernel): both engines, forward and inverse, raw FP64 hand-off"""
+    """the 8- and 7-stage passes of two-pass plans through ntt_r16.h (both passes at N = 2^14 .. 2^16, the first at 2^17) and the
+    9-stage second pass of N = 2^17 as three radix-8 groups per point: both engines, forward and inverse, raw FP64 hand-off"""
     D = params.CKKS_DEFAULT[65536]
     B = params.CKKS_BOOTSTRAP_65536
     if logn == 17:
