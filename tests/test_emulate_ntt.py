@@ -73,15 +73,17 @@ def test_fp64_engine_matches_oracle(emu, logn, tau):
     _check(emu, logn, tau, mods, fp64=3)   # the interleaved workgroup order of mixed-engine launches
 
 
-@pytest.mark.parametrize("logn", [14, 15, 16, 17])
+@pytest.mark.parametrize("logn", [14, 15, 16, 17, 18])
 def test_radix16_squared_passes_match_oracle(emu, logn):
     """the 8- and 7-stage passes of two-pass plans through ntt_r16.h (both passes at N = 2^14 .. 2^16, the first at 2^17) and the
     9-stage second pass of N = 2^17 as three radix-8 groups per point: both engines, forward and inverse, raw FP64 hand-off"""
     D = params.CKKS_DEFAULT[65536]
     B = params.CKKS_BOOTSTRAP_65536
-    if logn == 17:
+    if logn >= 17:   # (2^18: nine-stage first pass on the staged kernel, nine-stage second pass as three radix-8 groups)
         P = params.ckks_n17_chain()
-        mods = [P["q"][0], P["q"][1], P["p"][0]]
+        mods = [m for m in (P["q"][0], P["q"][1], P["p"][0]) if (m - 1) % (2 << logn) == 0]
+        if len(mods) < 2:
+            pytest.skip("the generated N = 2^17 chain has no two primes = 1 mod 2^%d" % (logn + 1))
     else:
         mods = [D["q"][1], B["q"][10], B["q"][0], B["p"][0]]   # 46- and 39-bit (FP64 engine), 60- and 61-bit (integer engine)
     _check(emu, logn, 12, mods, fp64=4 | 1)
