@@ -14,7 +14,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["lattisense_amd/csrc/kernels.hip", "lattisense_amd/csrc/ntt_core.h", "lattisense_amd/csrc/ntt_r16.h",
                   "lattisense_amd/csrc/modarith.h", "lattisense_amd/csrc/ops.hip"]
-NTT_KERNELS = ("k_ntt_r16", "k_ntt_pass")   # the limb-transform passes: radix-16-squared (8-stage passes) and the staged kernel
+NTT_KERNELS = ("k_ntt_r16", "k_ntt_r8x3", "k_ntt_pass")   # the limb-transform passes: radix-16-squared (8- / 7-stage), three radix-8 groups (9-stage), the staged kernel
 
 
 def sources_hash():
@@ -66,7 +66,7 @@ def main(d, out_dir, workload="ckks_hmult", batch=256):
     if "k_ntt_pass" in alg:
         ratios["k_ntt_pass"] = {"counter_bytes_per_launch": weighted, "algorithmic_bytes_per_launch": alg["k_ntt_pass"],
                                 "ratio": weighted / alg["k_ntt_pass"]}
-    res = {"kernel": "k_ntt_r16 + k_ntt_pass (every limb-transform pass, launch-weighted)", "workload": workload, "batch": int(batch), "variants": ntt,
+    res = {"kernel": "k_ntt_r16 + k_ntt_r8x3 + k_ntt_pass (every limb-transform pass, launch-weighted)", "workload": workload, "batch": int(batch), "variants": ntt,
            "hbm_bytes_per_launch": weighted, "other_kernels": {k: v for k, v in kernels.items() if not k.startswith(NTT_KERNELS)},
            "counter_vs_algorithmic": ratios,
            "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE exact; units KB",

@@ -12,7 +12,7 @@ def find(d, pat):
 
 def short(name):
     n = name.split("(")[0]
-    for fam in ("k_ntt_r16", "k_ntt_pass"):   # keep the variant (template arguments)
+    for fam in ("k_ntt_r16", "k_ntt_r8x3", "k_ntt_pass"):   # keep the variant (template arguments)
         if fam in n:
             return n[n.index(fam):]
     for k in ("k_ntt_pass", "k_baseconv", "k_ks_mac", "k_tensor", "k_sub_mul", "k_rescale_prep", "k_permute",
@@ -30,7 +30,7 @@ def main(d):
             print("%-18s calls=%-7s total_ms=%-10.3f avg_us=%-9.3f pct=%s" % (
                 short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
                 r["Percentage"]))
-        ntt = [r for r in rows if "k_ntt_pass" in r["Name"] or "k_ntt_r16" in r["Name"]]
+        ntt = [r for r in rows if "k_ntt_pass" in r["Name"] or "k_ntt_r16" in r["Name"] or "k_ntt_r8x3" in r["Name"]]
         if ntt:   # both variants together: the figure bench.py's roofline.avg_launch_us is compared with
             calls = sum(int(r["Calls"]) for r in ntt)
             tot = sum(float(r["TotalDurationNs"]) for r in ntt)
