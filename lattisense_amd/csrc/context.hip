@@ -314,6 +314,20 @@ const u64* Context::pinv_vec(int level) {
 }
 
 // q_level^-1 mod q_i for i < level (rescale tail), Montgomery form
+const u64* Context::pmodq_vec(int level) {
+    const int L = level + 1;
+    std::vector<int> mods(L);
+    std::vector<u64> pm(L);
+    for (int j = 0; j < L; j++) {
+        mods[j] = j;
+        const u64 q = T.mod[j];
+        u64 pr = 1;
+        for (int l = 0; l < np; l++) pr = mul_mod_host(pr, T.mod[p_mod(l)] % q, q);
+        pm[j] = pr;
+    }
+    return const_vec("pmodq" + std::to_string(L), mods, pm);
+}
+
 const u64* Context::qlinv_vec(int level) {
     std::vector<int> mods(level);
     std::vector<u64> v(level);

@@ -1340,17 +1340,7 @@ void launch_ks_mac(Context& c, int level, const u64* cx, long long scx, const u6
     KsMacArgs g{};
     LSA_REQUIRE(!scatter || (engine < 0 && base), "key MAC: the extended output covers every target limb and needs the ciphertext");
     if (scatter) {
-        const int L = level + 1;
-        std::vector<int> mods(L);
-        std::vector<u64> pm(L);
-        for (int j = 0; j < L; j++) {
-            mods[j] = j;
-            const u64 q = c.T.mod[j];
-            u64 pr = 1;
-            for (int l = 0; l < c.np; l++) pr = mul_mod_host(pr, c.T.mod[c.p_mod(l)] % q, q);
-            pm[j] = pr;
-        }
-        g.pm = c.const_vec("pmodq" + std::to_string(L), mods, pm);
+        g.pm = c.pmodq_vec(level);
         g.scatter = scatter;
         g.base = base;
         g.sbase = sbase;
@@ -1670,16 +1660,7 @@ void launch_permute_ext(Context& c, int level, const u32* perm, const u64* acc, 
     g.logn = c.logn;
     g.accumulate = accumulate ? 1 : 0;
     g.base_polys = base_polys;
-    std::vector<int> mods(L);
-    std::vector<u64> pm(L);
-    for (int j = 0; j < L; j++) {
-        mods[j] = j;
-        const u64 q = c.T.mod[j];
-        u64 pr = 1;
-        for (int l = 0; l < c.np; l++) pr = mul_mod_host(pr, c.T.mod[c.p_mod(l)] % q, q);
-        pm[j] = pr;
-    }
-    g.pm = c.const_vec("pmodq" + std::to_string(L), mods, pm);
+    g.pm = c.pmodq_vec(level);
     for (int tl = 0; tl < T; tl++) g.mod_of[tl] = (unsigned char)(tl < L ? tl : c.p_mod(tl - L));
     const double streams = (acc ? 1.0 : 0.0) * 2 * T + (double)base_polys * L + (accumulate ? 2.0 : 1.0) * 2 * T;
     ProfScope ps(c, PROF_ELEMWISE, 8.0 * c.n * streams * batch, s);

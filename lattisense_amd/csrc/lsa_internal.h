@@ -154,6 +154,7 @@ struct Context {
     const BaseConvPlan* baseconv(const std::vector<int>& src, const std::vector<int>& dst, bool centered,
                                  bool pinv_scaled = false, const BaseConvFold* fold = nullptr);
     const u64* pinv_vec(int level);
+    const u64* pmodq_vec(int level);   // [level+1] P mod q_j, Montgomery form (extended ciphertexts: c0 * P)
     const u64* qlinv_vec(int level);
     const u32* ntt_perm(u64 g);
     const u32* coeff_perm(u64 g);
