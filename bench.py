@@ -18,7 +18,7 @@ Multi-GPU (torchrun, one rank per GPU): the ciphertext batch is sharded by index
 no steady-state collective; rank 0 "ingests" the evaluation key and broadcasts it once over RCCL/xGMI.
 
 The JSON line also carries
-  roofline     — the limb-transform passes (k_ntt_r16 / k_ntt_pass, the dominant kernel family): algorithmic bytes / HIP-event
+  roofline     — the limb-transform passes (k_ntt_r16 / k_ntt_r8x3 / k_ntt_pass, the dominant kernel family): algorithmic bytes / HIP-event
                  duration, sampled live on the launch stream; `traffic` from the committed PMC passes of the same command
   cpu_baseline — the CPU oracle ("port") timed on rank 0's host cores on a bounded sample of the same workload.
 """
@@ -601,7 +601,7 @@ def main():
         ntt_primary = byp.value / ms0 / 1e6
     roofline = None
     if ntt:
-        roofline = {"kernel": "k_ntt_r16 / k_ntt_pass (limb-transform passes)", "bound": "hbm", "achieved": ntt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+        roofline = {"kernel": "k_ntt_r16 / k_ntt_r8x3 / k_ntt_pass (limb-transform passes)", "bound": "hbm", "achieved": ntt["achieved_GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": ntt["achieved_GBps"] / HBM_PEAK_GBPS, "traffic": None,
                     "avg_launch_us": ntt["avg_launch_us"], "launches_per_step": ntt["launches_per_step"],
                     # `achieved` counts the algorithmic bytes of everything these launches do: the transform passes (16 N / 2 per
