@@ -1,5 +1,6 @@
 #!/bin/bash
-# every bench workload once on the GPU box; one JSON line each into gpurun_out/workloads_<tag>.log
+# every bench workload once on the GPU box; one JSON line each into gpurun_out/workloads_<tag>.log, the summary table on stdout
+# (redirect stdout to ANOTHER file, e.g. tools/run_workloads.sh r03 > gpurun_out/workloads_r03_table.log)
 TAG=${1:-run}
 OUT=gpurun_out/workloads_$TAG.log
 : > $OUT
