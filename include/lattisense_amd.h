@@ -164,12 +164,14 @@ int lsa_bootstrap_galois_elements(lsa_bootstrap b, uint64_t* out, int capacity);
 /* the plan's floating-point constants, exported so that a checker can replay the program with the same integers */
 int lsa_bootstrap_chebyshev(lsa_bootstrap b, double* out32);
 int lsa_bootstrap_matrix_info(lsa_bootstrap b, int index, int* level, int* n1, int* n_diagonals, int* diagonals, int capacity);
-/* rows of the matrix's plaintexts: level + 1, or level + 1 + k for a baby-step / giant-step matrix of a double-hoisting plan
- * (the default; LSA_BT_DOUBLE_HOIST=0 at plan creation turns it off): the residues at the special primes follow those at
- * q_0..q_level, because the inner sums are formed over Q u P before ONE division by P per giant step (Lattigo v4
- * ckks/linear_transform.go, MultiplyByDiagMatrixBSGS).  lsa_bootstrap_plaintext writes rows * N words. */
-int lsa_bootstrap_plaintext_rows(lsa_bootstrap b, int matrix, int* rows);
+/* lsa_bootstrap_plaintext writes the (level + 1) * N words at q_0..q_level.  A baby-step / giant-step matrix of a double-hoisting
+ * plan (the default; LSA_BT_DOUBLE_HOIST=0 at plan creation turns it off) also carries the residues at the k special primes, because
+ * its inner sums are formed over Q u P before ONE division by P per giant step (Lattigo v4 ckks/linear_transform.go,
+ * MultiplyByDiagMatrixBSGS): lsa_bootstrap_plaintext_rows reports level + 1 or level + 1 + k, lsa_bootstrap_plaintext_ext writes
+ * all rows * N words (capacity checked). */
 int lsa_bootstrap_plaintext(lsa_bootstrap b, int matrix, int diag_pos, uint64_t* host_out);
+int lsa_bootstrap_plaintext_rows(lsa_bootstrap b, int matrix, int* rows);
+int lsa_bootstrap_plaintext_ext(lsa_bootstrap b, int matrix, int diag_pos, uint64_t* host_out, long long capacity_words);
 int lsa_ckks_bootstrap(lsa_context ctx, lsa_bootstrap b, const uint64_t* in, uint64_t* out, int batch, long long sin, long long sout,
                        lsa_key rlk, int n_glk, const uint64_t* glk_elements, const lsa_key* glk, lsa_key swk_dts, lsa_key swk_std,
                        void* stream);

@@ -96,6 +96,7 @@ SIGNATURES = {
                                           ctypes.POINTER(c_int), c_int]),
     "lsa_bootstrap_plaintext": (c_int, [c_vp, c_int, c_int, c_u64p]),
     "lsa_bootstrap_plaintext_rows": (c_int, [c_vp, c_int, ctypes.POINTER(c_int)]),
+    "lsa_bootstrap_plaintext_ext": (c_int, [c_vp, c_int, c_int, c_u64p, ctypes.c_longlong]),
     "lsa_ckks_bootstrap": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, ctypes.c_longlong, ctypes.c_longlong, c_vp, c_int, c_u64p,
                                    ctypes.POINTER(c_vp), c_vp, c_vp, c_vp]),
     "lsa_profile_begin": (c_int, [c_vp, c_int]),

@@ -478,9 +478,22 @@ int lsa_bootstrap_plaintext(lsa_bootstrap b, int matrix, int diag_pos, uint64_t*
         int lv, n1v;
         const std::vector<int>* ks;
         const std::vector<u64*>* pl;
-        int rows = 0;
+        bootstrap_matrix(*b->b, matrix, &lv, &n1v, &ks, &pl);
+        LSA_REQUIRE(diag_pos >= 0 && diag_pos < (int)pl->size(), "diagonal position out of range");
+        b->c->use_device();
+        // the rows at q_0..q_level only, whatever the plan keeps behind them: what this entry point has always written
+        LSA_HIP(hipMemcpy(host_out, (*pl)[diag_pos], (size_t)(lv + 1) * b->c->n * sizeof(u64), hipMemcpyDeviceToHost));
+    });
+}
+int lsa_bootstrap_plaintext_ext(lsa_bootstrap b, int matrix, int diag_pos, uint64_t* host_out, long long capacity_words) {
+    return guard([&] {
+        LSA_REQUIRE(b != nullptr && host_out != nullptr, "null argument");
+        int lv, n1v, rows = 0;
+        const std::vector<int>* ks;
+        const std::vector<u64*>* pl;
         bootstrap_matrix(*b->b, matrix, &lv, &n1v, &ks, &pl, &rows);
         LSA_REQUIRE(diag_pos >= 0 && diag_pos < (int)pl->size(), "diagonal position out of range");
+        LSA_REQUIRE(capacity_words >= (long long)rows * b->c->n, "buffer too small for the plaintext's rows (lsa_bootstrap_plaintext_rows)");
         b->c->use_device();
         LSA_HIP(hipMemcpy(host_out, (*pl)[diag_pos], (size_t)rows * b->c->n * sizeof(u64), hipMemcpyDeviceToHost));
     });

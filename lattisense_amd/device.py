@@ -266,7 +266,7 @@ class BootstrapPlan:
         check(lib().lsa_bootstrap_plaintext_rows(self.h, index, ctypes.byref(rows)))
         for i, k in enumerate(ks):
             pt = np.empty((rows.value, self.ctx.n), dtype=np.uint64)
-            check(lib().lsa_bootstrap_plaintext(self.h, index, i, pt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+            check(lib().lsa_bootstrap_plaintext_ext(self.h, index, i, pt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), pt.size))
             plains[int(k)] = pt
         return lv.value, n1.value, [int(k) for k in ks], plains
 
